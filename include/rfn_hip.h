@@ -1,0 +1,143 @@
+/* rfn_hip.h — C ABI of librfn_hip.so: hand-written gfx950 (MI355X / CDNA4) kernels for the RFN hot path.
+ *
+ * The reference (cdglissov/recurrent-flows-msc) has no FFI: its boundary for this path is the Python class API of
+ * `Flow/glow_modules.py`, `Flow/glow.py` and `Utils/modules.py` (ConvLSTM).  Each entry point below replaces the
+ * torch-op sequence of the cited reference lines; the Python host side (recurrent-flows-msc_amd/{Flow,Utils,RFN})
+ * keeps the reference's class names, signatures and state_dict keys and calls these through ctypes
+ * (recurrent-flows-msc_amd/rfn_hip/lib.py).  See INTEGRATION.md for the binding a maintainer would add.
+ *
+ * Conventions
+ *   - every tensor is fp32, NCHW, device memory, 4-byte aligned; "ns" arguments are the frame (dim-0) stride in
+ *     ELEMENTS, so a channel-slice view of a bigger tensor can be passed without a copy; the channel stride is H*W;
+ *   - N is the number of frames in the launch (the host time-batches B*(T-1) frames), HW = H*W;
+ *   - all functions enqueue on `stream` (a hipStream_t passed as void*) and never synchronise or allocate;
+ *   - return value: 0 on success, otherwise a hipError_t / negative argument-check code; rfn_last_error() gives text;
+ *   - no global state besides the last-error string; safe to call from several host threads on distinct streams.
+ */
+#ifndef RFN_HIP_H
+#define RFN_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef void* rfn_stream_t;
+
+int rfn_abi_version(void);
+const char* rfn_last_error(void);
+
+/* ---- a1  Squeeze2d.forward  (Flow/glow_modules.py:298-310): out[b,4c+2i+j,h,w] = in[b,c,2h+i,2w+j]; undo = inverse.
+ * C,H,W are the INPUT dims.  x_ns / y_ns: frame strides of input / output. Bit-exact copy. */
+int rfn_squeeze2d_f32(const float* x, long x_ns, float* y, long y_ns, int N, int C, int H, int W, int undo,
+                      rfn_stream_t stream);
+
+/* ---- a3  ActNorm.initialize  (glow_modules.py:22-31): per-channel mean and UNBIASED variance over (N,H,W).
+ * mean[C], var[C] are overwritten. */
+int rfn_channel_stats_f32(const float* x, long x_ns, float* mean, float* var_unbiased, int N, int C, int HW,
+                          rfn_stream_t stream);
+
+/* ---- a3+a4  ActNorm.forward + InvConv.forward fused  (glow_modules.py:38-45, 209-216):
+ *   y = (x + bias[c]) * exp(logs[c]);  z[n,:,p] = Wm · y[n,:,p]      (Wm is the C×C matrix built on the host from
+ *   P,L,U,log_s, glow_modules.py:188-205).  The log-det terms (Σlogs + Σlog_s)·HW are parameter-only and are added
+ *   by the host. */
+int rfn_actnorm_invconv_fwd_f32(const float* x, long x_ns, const float* bias, const float* logs, const float* Wm,
+                                float* z, long z_ns, int N, int C, int HW, rfn_stream_t stream);
+/* backward of the above: given gz, recomputes y; gx = exp(logs)·Wmᵀgz; gW += Σ gz yᵀ; gbias += Σ gy·exp(logs);
+ * glogs += Σ gy·y.  gW[C*C], gbias[C], glogs[C] are ACCUMULATED into (caller zeroes them). */
+int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const float* bias, const float* logs, const float* Wm,
+                                const float* gz, long gz_ns, float* gx, long gx_ns, float* gW, float* gbias,
+                                float* glogs, int N, int C, int HW, rfn_stream_t stream);
+/* reverse direction (glow_modules.py:47-52, 217-221):  x = (Winv · z) * exp(-logs) - bias. */
+int rfn_invconv_actnorm_rev_f32(const float* z, long z_ns, const float* bias, const float* logs, const float* Winv,
+                                float* x, long x_ns, int N, int C, int HW, rfn_stream_t stream);
+
+/* ---- a5.1/a5.2  Conv2dNorm / Conv2dZeros / ConvLSTM conv  (glow_modules.py:106-147, Utils/modules.py:335-340,368):
+ * implicit-GEMM convolution on fp32 MFMA (v_mfma_f32_32x32x2_f32), stride 1, "same" padding, ks ∈ {1,3}.
+ * Input channels [0,C1) are read from in1, [C1,C1+C2) from in2 (the torch.cat of glow_modules.py:273,355 and
+ * Utils/modules.py:367 is never materialised); in2 may be NULL when C2 == 0.
+ * wpk: weights packed by rfn_pack_conv_weight_f32.
+ * Output channels [0,cout_split) go to out1, [cout_split,Cout) to out2 (out2 may be NULL when cout_split == Cout);
+ * acc1/acc2 != 0 accumulates (out += result) instead of overwriting.
+ * Epilogue (ep_mode), applied per output channel c before the store:
+ *   0: y = a                                   (plain; used for dgrad)
+ *   1: y = act((a + p0[c]) * exp(p1[c]))       (Conv2dNorm = conv + ActNorm, then ActFun; act 0 none,1 relu,2 leaky .2)
+ *   2: y = (a + p0[c]) * exp(3*p1[c])          (Conv2dZeros)
+ *   3: y = a + p0[c]                           (conv with bias; ConvLSTM)
+ */
+int rfn_conv2d_fwd_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                       const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                       int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
+                       const float* p0, const float* p1, int act, rfn_stream_t stream);
+
+/* number of floats of a packed weight buffer for (Cout, Cin, ks) */
+long rfn_packed_weight_size(int Cout, int Cin, int ks);
+/* Pack torch-layout weights w[Cout][Cin][ks][ks] for rfn_conv2d_fwd_f32.
+ * transpose_flip = 0: forward conv.  transpose_flip = 1: the data-gradient conv (roles of Cin/Cout swapped, taps
+ * mirrored), i.e. the packed buffer then describes a conv with Cin'=Cout inputs and Cout'=Cin outputs. */
+int rfn_pack_conv_weight_f32(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
+                             rfn_stream_t stream);
+
+/* weight gradient, tap-major: gwt[ks*ks][Cout][Cin] += Σ_{n,y,x} g[n,co,y,x] · in[n,ci,y+dy,x+dx]  (two-source
+ * input as above).  gwt is ACCUMULATED into with float atomics (caller zeroes it); tap-major so that one MFMA
+ * accumulator register is a contiguous 128-byte atomic segment. */
+int rfn_conv2d_wgrad_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                         const float* g, long g_ns, int Cout, float* gwt, int N, int H, int W, int ks,
+                         rfn_stream_t stream);
+/* gw[Cout][Cin][ks][ks] (torch layout) = (accumulate ? gw : 0) + transpose of gwt[ks*ks][Cout][Cin]. */
+int rfn_wgrad_finish_f32(const float* gwt, float* gw, int Cout, int Cin, int ks, int accumulate, rfn_stream_t stream);
+
+/* backward through  y = act((u + b[c]) * exp(l[c]))  (ep_mode 1) or  y = (u + b[c]) * exp(3 l[c])  (ep_mode 2),
+ * given y (saved forward output) and gy:   gu (may alias gy) ;  gb[c] += ...;  gl[c] += ...  (accumulated). */
+int rfn_conv_epilogue_bwd_f32(const float* y, long y_ns, const float* gy, long gy_ns, float* gu, long gu_ns,
+                              const float* logs, float* gb, float* gl, int N, int C, int HW, int ep_mode, int act,
+                              rfn_stream_t stream);
+
+/* ---- a5  AffineCoupling.forward, everything after the coupling net  (glow_modules.py:276-291):
+ * o = NN output [N,C,HW] with shift = o[:,0::2], s = o[:,1::2];  ls = clamp(s) (clamp_type 0 realnvp:
+ * scale[c]*tanh(s)+scale_shift[c]; 1 glow: log sigmoid(s+2); 2 softclamp: 2.5*0.636*atan(s/2.5); 3 none);
+ * forward (reverse=0): z2 <- (z2 + shift) * exp(ls), logdet[n] += Σ ls;  reverse=1: z2 <- z2*exp(-ls) - shift,
+ * logdet[n] -= Σ ls.   z2 = channels [C/2, C) of z, updated IN PLACE.  logdet may be NULL. */
+int rfn_affine_coupling_f32(float* z, long z_ns, const float* o, long o_ns, const float* scale,
+                            const float* scale_shift, float* logdet, int clamp_type, int reverse, int N, int C, int HW,
+                            rfn_stream_t stream);
+/* backward of the forward direction.  zout = output of the forward (z1 | z2'), gout = grad wrt it, glogdet[N] = grad
+ * wrt logdet.  Writes gz2 into channels [C/2,C) of gz (channels [0,C/2) of gz are NOT touched), go [N,C,HW] (grad wrt
+ * the NN output) and accumulates gscale[C/2], gscale_shift[C/2]. */
+int rfn_affine_coupling_bwd_f32(const float* zout, long zout_ns, const float* o, long o_ns, const float* gout,
+                                long gout_ns, const float* glogdet, const float* scale, const float* scale_shift,
+                                float* gz, long gz_ns, float* go, long go_ns, float* gscale, float* gscale_shift,
+                                int clamp_type, int N, int C, int HW, rfn_stream_t stream);
+
+/* ---- a7/a8  Gaussian log-likelihood reductions  (glow_modules.py:358-365, glow.py:135-140):
+ * logp[n] += Σ_{c,p} log N(z[n,c,p]; mean, std).
+ *   layout 0 ("cross", Split2d): mean = o[:,2c], raw = o[:,2c+1];  layout 1 ("split", base prior): mean = o[:,c],
+ *   raw = o[:,Cz+c].   std_mode 0: softplus(raw)+1e-8 ; 1: exp(raw).   o has 2*Cz channels, z has Cz. */
+int rfn_gauss_logp_f32(const float* z, long z_ns, const float* o, long o_ns, float* logp, int layout, int std_mode,
+                       int N, int Cz, int HW, rfn_stream_t stream);
+/* backward: gz (written) and go (written) from glogp[N]. */
+int rfn_gauss_logp_bwd_f32(const float* z, long z_ns, const float* o, long o_ns, const float* glogp, float* gz,
+                           long gz_ns, float* go, long go_ns, int layout, int std_mode, int N, int Cz, int HW,
+                           rfn_stream_t stream);
+/* reverse / sampling (glow_modules.py:366-369, glow.py:153-154): z = mean + std*temperature*eps. */
+int rfn_gauss_sample_f32(const float* o, long o_ns, const float* eps, float* z, long z_ns, float temperature, int layout,
+                         int std_mode, int N, int Cz, int HW, rfn_stream_t stream);
+
+/* ---- a9  ConvLSTMLayer.forward gate update  (Utils/modules.py:370-377): cc = conv output [N,4*Hc,HW] in gate order
+ * i,f,o,g;  i=σ(cc_i+Wci∘c) f=σ(cc_f+Wcf∘c) g=tanh(cc_g) c'=f∘c+i∘g o=σ(cc_o+Wco∘c') h'=o∘tanh(c').
+ * Wci/Wcf/Wco [Hc*HW] may be NULL (== 0, which is what the reference trains with).  gates [N,4*Hc,HW] receives the
+ * post-nonlinearity i,f,o,g for the backward pass (may be NULL). */
+int rfn_convlstm_gates_fwd_f32(const float* cc, const float* c_prev, long c_ns, const float* Wci, const float* Wcf,
+                               const float* Wco, float* h_out, long h_ns, float* c_out, long co_ns, float* gates,
+                               int N, int Hc, int HW, rfn_stream_t stream);
+/* backward: from gh, gc_next (either may be NULL), saved gates, c_prev, c_out -> gcc [N,4Hc,HW], gc_prev.
+ * The peephole terms enter the state gradients; gradients w.r.t. Wci/Wcf/Wco themselves are not produced (the
+ * reference never trains them on a GPU: Utils/modules.py:385-393 creates them as non-leaf tensors). */
+int rfn_convlstm_gates_bwd_f32(const float* gates, const float* c_prev, long c_ns, const float* c_out, long co_ns,
+                               const float* gh, long gh_ns, const float* gc_next, long gcn_ns, const float* Wci,
+                               const float* Wcf, const float* Wco, float* gcc, float* gc_prev, long gcp_ns, int N,
+                               int Hc, int HW, rfn_stream_t stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RFN_HIP_H */

@@ -1,0 +1,194 @@
+"""Multi-scale conditional Glow with the reference's surface (Flow/glow.py of the reference):
+`ListGlow(x_size, condition_size, base_dist_size, args)`, `.log_prob(x, condition, base_condition, logdet)`,
+`.sample(z, condition, base_condition, num_samples, temperature, eval_params)`, and the same `glow_frame` /
+`prior` module layout (hence the same state_dict keys).
+
+MI355X-first differences from the reference implementation (results are the same):
+  * a GlowStep is ONE autograd node (rfn_hip.ops.GlowStepFn) launching hand-written gfx950 kernels;
+  * `log_prob` accepts any number of frames N in dim 0 — the RFN driver time-batches all B·(T−1) frames into one call
+    so the MFMA convolutions see GEMM-N = N·H·W even at the 2×2 / 4×4 levels;
+  * no per-ActNorm `.item()` host syncs: initialisation state is mirrored on the host;
+  * parameter-only log-det terms of all K steps of a level are summed once, not once per step.
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from Utils import split_feature, ActFun
+from rfn_hip import ops as K
+from .glow_modules import (ActNorm, Conv2dZeros, Conv2dNorm, InvConv, AffineCoupling, Squeeze2d, Split2d,
+                           BatchNormFlow, add_logdet)
+
+
+class GlowStep(nn.Module):
+    """Flow/glow.py:10-41 — ActNorm → InvConv(LU) → AffineCoupling (reverse: inverted order)."""
+
+    def __init__(self, x_size, condition_size, args):
+        super().__init__()
+        b, c, h, w = x_size
+        self.flow_norm = args.flow_norm
+        if args.flow_norm == "batchnorm":
+            self.norm = BatchNormFlow(x_size, momentum=args.flow_batchnorm_momentum)
+        else:
+            self.norm = ActNorm(c)
+        self.invconv = InvConv(c, LU_decomposed=args.LU_decomposed)
+        self.affine = AffineCoupling(x_size, condition_size, hidden_units=args.n_units_affine,
+                                     non_lin=args.non_lin_glow, clamp_type=args.clamp_type)
+
+    def _param_logdet(self, x):
+        """(Σ actnorm.logs + Σ log_s)·H·W — the log-det terms that do not depend on the data."""
+        hw = x.shape[2] * x.shape[3]
+        if self.invconv.LU_decomposed:
+            ld = torch.sum(self.invconv.log_s)
+        else:
+            ld = torch.slogdet(self.invconv.weight)[1]
+        return (ld + torch.sum(self.norm.logs)) * hw
+
+    def forward(self, x, condition, logdet, reverse):
+        if self.flow_norm == "batchnorm":  # non-default variant: unfused module chain
+            if not reverse:
+                x, logdet = self.norm(x, logdet, reverse=False)
+                x, logdet = self.invconv(x, logdet, reverse=False)
+                return self.affine(x, condition, logdet, reverse=False)
+            x, logdet = self.affine(x, condition, logdet, reverse=True)
+            x, logdet = self.invconv(x, logdet, reverse=True)
+            return self.norm(x, logdet, reverse=True)
+        aff, an = self.affine, self.norm
+        act, clamp = K.ACT[aff.non_lin], K.CLAMP[aff.clamp_type]
+        x = x if x.stride(-1) == 1 and x.stride(1) == x.shape[2] * x.shape[3] else x.contiguous()
+        condition = condition.contiguous()
+        if not reverse:
+            if an.needs_init():  # data dependent init, first training call (glow_modules.py:22-36)
+                an.initialize(x)
+                an.mark_initialized()
+            Wm, _ = self.invconv.get_weight(x, reverse=False)
+            if aff.net[0].norm_type.needs_init() or aff.net[2].norm_type.needs_init():
+                with torch.no_grad():
+                    z = K.actnorm_invconv_fwd(x.detach(), an.bias.detach().reshape(-1), an.logs.detach().reshape(-1),
+                                              Wm.detach())
+                    aff.maybe_init(z[:, : z.shape[1] // 2], condition)
+            out, dl = K.GlowStepFn.apply(x, condition, Wm, an.bias, an.logs, *aff.nn_params(), act, clamp)
+            if logdet is not None:
+                logdet = logdet + dl + self._param_logdet(x)
+            return out, logdet
+        if an.needs_init():
+            an.mark_initialized()  # the reference flips the flag on any first call (glow_modules.py:34-36)
+        for m in (aff.net[0].norm_type, aff.net[2].norm_type):
+            if m.needs_init():
+                m.mark_initialized()
+        Winv, _ = self.invconv.get_weight(x, reverse=True)
+        out, dl = K.GlowStepRevFn.apply(x, condition, Winv, an.bias, an.logs, *aff.nn_params(), act, clamp)
+        if logdet is not None:
+            logdet = logdet + dl - self._param_logdet(x)
+        return out, logdet
+
+
+class ListGlow(nn.Module):
+    """Flow/glow.py:43-160."""
+
+    def __init__(self, x_size, condition_size, base_dist_size, args):
+        super().__init__()
+        assert isinstance(condition_size, list), "condition_size is not a list, make sure it fits L"
+        self.learn_prior = args.learn_prior
+        self.n_units_prior = args.n_units_prior
+        self.make_conditional = args.make_conditional
+        self.base_norm = args.base_norm
+        self.non_lin_glow = args.non_lin_glow
+        self.conditional_clamp_function = args.split2d_act
+        self.L, self.K, self.n_bits = args.L, args.K, args.n_bits
+        Bx, Cx, Hx, Wx = x_size
+        Bc, Cc, Hc, Wc = base_dist_size
+        layers = []
+        for l in range(self.L):
+            layers.append(Squeeze2d())
+            Cx, Hx, Wx = Cx * 4, Hx // 2, Wx // 2
+            size = [Bx, Cx, Hx, Wx]
+            for _ in range(self.K):
+                layers.append(GlowStep(size, condition_size[l], args))
+            if l < self.L - 1:
+                layers.append(Split2d(size, condition_size[l], self.make_conditional, self.conditional_clamp_function))
+                Cx = Cx // 2
+        self.glow_frame = nn.ModuleList(layers)
+        self.z_shape = (Cx, Hx, Wx)
+        if self.learn_prior:
+            self.prior = nn.Sequential(
+                Conv2dNorm(Cc, self.n_units_prior, norm=self.base_norm),
+                ActFun(self.non_lin_glow),
+                Conv2dNorm(self.n_units_prior, self.n_units_prior // 2, norm=self.base_norm),
+                ActFun(self.non_lin_glow),
+                Conv2dZeros(in_channel=self.n_units_prior // 2, out_channel=2 * Cx),
+            )
+
+    # ---- x -> z ------------------------------------------------------------------------------------------
+    def f(self, x, condition, logdet):
+        """Flow/glow.py:105-117."""
+        z, l = x, 0
+        for step in self.glow_frame:
+            if isinstance(step, Squeeze2d):
+                z = step(z, undo_squeeze=False)
+            elif isinstance(step, Split2d):
+                z, logdet = step(z, condition[l], logdet=logdet, reverse=False)
+                l += 1
+            else:
+                z, logdet = step(z, condition[l], logdet=logdet, reverse=False)
+        return z, logdet
+
+    # ---- z -> x ------------------------------------------------------------------------------------------
+    def g(self, z, condition, logdet, temperature, eps_list=None):
+        """Flow/glow.py:90-102.  `eps_list` (optional) pins the N(0,1) draws of the Split2d layers, coarsest first."""
+        x, l = z, len(condition) - 1
+        eps_list = list(eps_list) if eps_list is not None else None
+        for step in reversed(self.glow_frame):
+            if isinstance(step, Squeeze2d):
+                x = step(x, undo_squeeze=True)
+            elif isinstance(step, Split2d):
+                l -= 1
+                e = eps_list.pop(0) if eps_list else None
+                x, logdet = step(x, condition[l], logdet=logdet, reverse=True, temperature=temperature, eps=e)
+            else:
+                x, logdet = step(x, condition[l], logdet=logdet, reverse=True)
+        return x, logdet
+
+    def uniform_binning_correction(self, x, noise=None):
+        """Flow/glow.py:119-126 — dequantisation: x + U(0, 1/2^n_bits), objective −ln(2^n_bits)·C·H·W."""
+        b, c, h, w = x.size()
+        n_bins = 2 ** self.n_bits
+        if noise is None:
+            noise = torch.rand(x.shape, device=x.device, dtype=x.dtype) * (1.0 / n_bins)
+        objective = torch.full((b,), -np.log(n_bins) * (c * h * w), device=x.device, dtype=torch.float32)
+        return x + noise, objective
+
+    def _base_params(self, base_condition, n, device):
+        if self.learn_prior:
+            h = self.prior[0](base_condition.contiguous(), act=self.non_lin_glow)
+            h = self.prior[2](h, act=self.non_lin_glow)
+            return self.prior[4](h)  # [n, 2*Cz, h, w]: "split" halves = (mean, log_scale)
+        return torch.zeros((n, 2 * self.z_shape[0]) + self.z_shape[1:], device=device)
+
+    def log_prob(self, x, condition, base_condition, logdet=0, noise=None):
+        """Flow/glow.py:128-141.  `noise` optionally pins the dequantisation draw (tests / parity runs)."""
+        x, obj_unif = self.uniform_binning_correction(x, noise)
+        assert isinstance(condition, list), "Condition is not a list, make sure it fits L"
+        z, obj = self.f(x, condition, logdet)
+        obj = obj + obj_unif
+        params = self._base_params(base_condition, x.shape[0], x.device)
+        obj = obj + K.GaussLogpFn.apply(z.contiguous(), params, 1, 1)
+        return z, -obj
+
+    def sample(self, z, condition, base_condition, num_samples=32, temperature=0.8, eval_params=False, eps_base=None,
+               eps_list=None):
+        """Flow/glow.py:143-160."""
+        with torch.no_grad():
+            mean = log_scale = None
+            if z is None:
+                n = base_condition.shape[0] if self.learn_prior else num_samples
+                dev = base_condition.device if base_condition is not None else condition[0].device
+                params = self._base_params(base_condition, n, dev)
+                mean, log_scale = split_feature(params, "split")
+                if eps_base is None:
+                    eps_base = torch.randn(mean.shape, device=dev)
+                z = K.gauss_sample(params, eps_base, 1, 1, temperature)
+            x, _ = self.g(z, condition, logdet=None, temperature=temperature, eps_list=eps_list)
+        if eval_params:
+            return x, (mean, torch.exp(log_scale))
+        return x

@@ -1,0 +1,290 @@
+"""RFN — recurrent flow network (SRNN latent dynamics + conditional Glow decoder) with the reference's surface:
+`RFN(args)`, `.loss(x, logdet) -> (kl_free_bit, kl, nll)` (also exposed as `.forward`), `.predict`, `.reconstruct`,
+`.sample`; same sub-module names, hence the same state_dict keys (RFN/RFN_new.py of the reference).
+
+MI355X-first restructuring of `loss` (same mathematics, RFN/RFN_new.py:116-247):
+  1. extractor over the T frames, ConvLSTM over t (HIP cell), optional backward smoothing LSTM;
+  2. the latent recurrence (prior / encoder at the coarsest resolution) and the upscaler run per t — they are the only
+     parts that are sequential through z_{t-1};
+  3. the Glow decoder — ≈84 % of the reference's time — is evaluated ONCE on all B·(T−1) frames, t-major
+     (`frame = (t-1)·B + b`), so every kernel launch carries the whole sequence batch.
+Data dependent ActNorm initialisation uses the first B frames (t = 1) exactly like the reference's first call.
+"""
+import torch
+import torch.nn as nn
+import torch.distributions as td
+
+from Flow import ListGlow
+from Flow.glow_modules import ActNorm
+from Utils import VGG_upscaler, VGG_downscaler, SimpleParamNet, ConvLSTM, free_bits_kl, batch_reduce
+
+
+class RFN(nn.Module):
+    def __init__(self, args):
+        super().__init__()
+        self.params = args
+        batch_size = args.batch_size
+        self.u_dim = args.x_dim
+        self.x_dim = args.condition_dim
+        self.h_dim, self.z_dim = args.h_dim, args.z_dim
+        self.beta = 1
+        self.L, self.K = args.L, args.K
+        self.temperature = args.temperature
+        self.free_bits = args.free_bits
+        self.skip_connection_flow = args.skip_connection_flow
+        self.skip_connection_features = args.skip_connection_features
+        self.kl_temperature = 1
+        self.a_dim = args.a_dim
+        self.enable_smoothing = args.enable_smoothing
+        self.res_q = args.res_q
+        self.D = args.D + 1
+        self.overshot_w = args.overshot_w
+        down_structure, up_structure = args.extractor_structure, args.upscaler_structure
+        nf = args.norm_type_features
+
+        self.single_feature = self.skip_connection_flow == "without_skip" and not self.skip_connection_features
+        self.extractor = VGG_downscaler(down_structure, L=self.L, in_channels=self.x_dim[1], norm_type=nf,
+                                        non_lin="relu", scale=args.structure_scaler,
+                                        skip_con=not self.single_feature, tanh=args.downscaler_tanh)
+        channel_dims = [i[-1] for i in up_structure][::-1]
+        dims_skip = self.extractor.get_layer_size(down_structure, self.x_dim)
+        hu, wu = self.u_dim[2], self.u_dim[3]
+        condition_size_list = []
+        for i in range(self.L):
+            hu, wu = hu // 2, hu // 2
+            if self.skip_connection_flow == "with_skip":
+                cc = channel_dims[i] + dims_skip[i][1]
+            elif self.skip_connection_flow == "without_skip":
+                cc = channel_dims[i]
+            elif self.skip_connection_flow == "only_skip":
+                cc = dims_skip[i][1]
+            else:
+                raise ValueError("choose skip setting")
+            condition_size_list.append([batch_size, cc, hu, wu])
+        c_features = dims_skip[-1][1]
+
+        # learnable initial states: batch-shaped, exactly as in the reference (RFN_new.py:69-76)
+        self.z_0 = nn.Parameter(torch.zeros(batch_size, self.z_dim, hu, wu))
+        self.z_0x = nn.Parameter(torch.zeros(batch_size, self.z_dim, hu, wu))
+        self.h_0 = nn.Parameter(torch.zeros(batch_size, self.h_dim, hu, wu))
+        self.c_0 = nn.Parameter(torch.zeros(batch_size, self.h_dim, hu, wu))
+        self.a_0 = nn.Parameter(torch.zeros(batch_size, self.a_dim, hu, wu))
+        self.ca_0 = nn.Parameter(torch.zeros(batch_size, self.a_dim, hu, wu))
+
+        self.upscaler = VGG_upscaler(up_structure, L=self.L, in_channels=self.h_dim + self.z_dim, norm_type=nf,
+                                     non_lin="leakyrelu", scale=args.structure_scaler,
+                                     skips=self.skip_connection_features, size_skips=dims_skip, tanh=args.upscaler_tanh)
+        self.lstm = ConvLSTM(in_channels=c_features, hidden_channels=self.h_dim, kernel_size=[3, 3], bias=True,
+                             peephole=True)
+        if self.enable_smoothing:
+            self.a_lstm = ConvLSTM(in_channels=c_features + self.h_dim, hidden_channels=self.a_dim,
+                                   kernel_size=[3, 3], bias=True, peephole=True)
+        self.prior = SimpleParamNet(args.prior_structure, in_channels=self.h_dim + self.z_dim,
+                                    out_channels=self.z_dim, norm_type=args.norm_type, non_lin="leakyrelu")
+        base_dim = (batch_size, self.h_dim + self.z_dim, hu, wu)
+        self.flow = ListGlow(self.x_dim, condition_size_list, base_dim, args=self.params)
+        enc_in = (self.a_dim + self.z_dim) if self.enable_smoothing else (c_features + self.h_dim + self.z_dim)
+        self.encoder = SimpleParamNet(args.encoder_structure, in_channels=enc_in, out_channels=self.z_dim,
+                                      norm_type=args.norm_type, non_lin="leakyrelu")
+
+    # ------------------------------------------------------------------------------------------------ helpers
+    def get_inits(self):
+        return self.h_0, self.c_0, self.a_0, self.ca_0, self.z_0, self.z_0x, 0, 0, 0
+
+    def _last(self, feats):
+        return feats if self.single_feature else feats[-1]
+
+    def combineconditions(self, flow_conditions, skip_conditions):
+        return [torch.cat((a, b), dim=1) for a, b in zip(flow_conditions, skip_conditions)]
+
+    def _flow_conditions(self, hz, feats_prev):
+        if self.skip_connection_features:
+            fc = self.upscaler(hz, skip_list=feats_prev)
+        else:
+            fc = self.upscaler(hz)
+        if self.skip_connection_flow == "with_skip":
+            fc = self.combineconditions(fc, feats_prev)
+        elif self.skip_connection_flow == "only_skip":
+            fc = feats_prev
+        return fc
+
+    def _deterministic_states(self, feats, n_steps, hprev, cprev, aprev, caprev):
+        """h_t for t = 1..n_steps-1 (RFN_new.py:131-139) and, with smoothing, the backward a_t (:142-153)."""
+        store_ht = []
+        for i in range(1, n_steps):
+            _, hprev, cprev = self.lstm(self._last(feats[i - 1]).unsqueeze(1), hprev, cprev)
+            store_ht.append(hprev)
+        store_at = [None] * (n_steps - 1)
+        if self.enable_smoothing:
+            for i in range(1, n_steps):
+                inp = torch.cat([store_ht[n_steps - i - 1], self._last(feats[n_steps - i])], 1)
+                _, aprev, caprev = self.a_lstm(inp.unsqueeze(1), aprev, caprev)
+                store_at[n_steps - i - 1] = aprev
+        return store_ht, store_at, hprev, cprev
+
+    def _flow_needs_init(self):
+        return any(m.needs_init() for m in self.flow.modules() if isinstance(m, ActNorm))
+
+    # ------------------------------------------------------------------------------------------------ training
+    def loss(self, x, logdet=0, draws=None):
+        """RFN/RFN_new.py:116-247.  `draws` (optional) = list of noise tensors in the reference's draw order
+        (per t: prior ε, encoder ε, dequantisation U; then the overshooting prior ε's) for parity runs."""
+        assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
+        B, T = x.shape[0], x.shape[1]
+        dev = x.device
+        draws = list(draws) if draws is not None else None
+
+        def eps_like(ref):
+            return draws.pop(0).to(dev) if draws is not None else torch.randn(ref.shape, device=dev)
+
+        hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
+        feats = [self.extractor(x[:, i]) for i in range(T)]
+        store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
+
+        kl_loss = 0
+        st_mean, st_std, st_zx = [], [], []
+        conds_t, base_t, noise_t = [], [], []
+        for i in range(1, T):
+            ht = store_ht[i - 1]
+            if self.enable_smoothing:
+                enc_mean, enc_std = self.encoder(torch.cat((store_at[i - 1], zxprev), dim=1))
+            else:
+                enc_mean, enc_std = self.encoder(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
+            if self.res_q:
+                prior_mean, prior_std = self.prior(torch.cat((ht, zxprev), dim=1))
+                enc_mean = prior_mean + enc_mean
+            else:
+                prior_mean, prior_std = self.prior(torch.cat((ht, zprev), dim=1))
+            zt = prior_mean + prior_std * eps_like(prior_mean)      # dist_prior.rsample()
+            zxt = enc_mean + enc_std * eps_like(enc_mean)           # dist_enc.rsample()
+            st_mean.append(enc_mean); st_std.append(enc_std); st_zx.append(zxprev)
+            hz = torch.cat((ht, zxt), dim=1)
+            conds_t.append(self._flow_conditions(hz, feats[i - 1]))
+            base_t.append(hz)
+            if draws is not None:
+                noise_t.append(draws.pop(0).to(dev))
+            if self.D == 1:
+                kl_loss = kl_loss + td.kl_divergence(td.Normal(enc_mean, enc_std), td.Normal(prior_mean, prior_std))
+            zprev, zxprev = zt, zxt
+
+        # ---- the decoder: all B*(T-1) frames in one call, t-major
+        xs = x[:, 1:].transpose(0, 1).reshape((T - 1) * B, *x.shape[2:])
+        conds = [torch.cat([c[l] for c in conds_t], dim=0) for l in range(self.L)]
+        base = torch.cat(base_t, dim=0)
+        noise = torch.cat(noise_t, dim=0) if noise_t else None
+        if self.training and self._flow_needs_init():
+            with torch.no_grad():  # data dependent init on the t = 1 batch, as the reference's first call does
+                self.flow.log_prob(xs[:B], [c[:B] for c in conds], base[:B], 0,
+                                   None if noise is None else noise[:B])
+        _, nll = self.flow.log_prob(xs, conds, base, logdet, noise)
+        nll_loss = nll.view(T - 1, B).sum(0)
+
+        if self.D > 1:  # overshooting (RFN_new.py:213-240)
+            kl_loss = 0
+            for i in range(1, T):
+                overshot_loss, idt, zp = 0, i - 1, st_zx[i - 1]
+                D = min(T - i, self.D)
+                for d in range(D):
+                    pm, ps = self.prior(torch.cat((store_ht[idt + d], zp), dim=1))
+                    zp = pm + ps * eps_like(pm)
+                    em, es = st_mean[idt + d], st_std[idt + d]
+                    if d > 0:
+                        em, es = em.detach().clone(), es.detach().clone()
+                    overshot_loss = overshot_loss + self.overshot_w * td.kl_divergence(td.Normal(em, es),
+                                                                                        td.Normal(pm, ps))
+                kl_loss = kl_loss + 1 / D * overshot_loss
+
+        kl_free_bit = free_bits_kl(kl_loss, free_bits=self.free_bits) if self.free_bits > 0 else kl_loss
+        return batch_reduce(kl_free_bit).mean(), batch_reduce(kl_loss).mean(), nll_loss.mean()
+
+    def forward(self, x, logdet=0):
+        """Alias of `loss` so wrappers that hook `forward` (gradient all-reduce) see the training call."""
+        return self.loss(x, logdet)
+
+    # ------------------------------------------------------------------------------------------------ generation
+    def _posterior_rollout(self, x, n_steps, feats, sample_prior=True):
+        """shared warm-up of predict(): run the SRNN over the first n_steps frames, return final states."""
+        hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
+        store_ht, store_at, hprev, cprev = self._deterministic_states(feats, n_steps, hprev, cprev, aprev, caprev)
+        for i in range(1, n_steps):
+            ht = store_ht[i - 1]
+            if self.enable_smoothing:
+                enc_mean, enc_std = self.encoder(torch.cat((store_at[i - 1], zxprev), dim=1))
+            else:
+                enc_mean, enc_std = self.encoder(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
+            if self.res_q:
+                prior_mean, prior_std = self.prior(torch.cat((ht, zxprev), dim=1))
+                enc_mean = prior_mean + enc_mean
+            else:
+                prior_mean, prior_std = self.prior(torch.cat((ht, zprev), dim=1))
+            zprev = prior_mean + prior_std * self.kl_temperature * torch.randn_like(prior_mean)
+            zxprev = enc_mean + enc_std * torch.randn_like(enc_mean)
+        return hprev, cprev, zprev, zxprev
+
+    def predict(self, x, n_predictions, n_conditions):
+        """RFN/RFN_new.py:256-360 — condition on n_conditions frames, roll the prior forward n_predictions frames."""
+        assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
+        with torch.no_grad():
+            feats = [self.extractor(x[:, i]) for i in range(n_conditions)]
+            hprev, cprev, zprev, _ = self._posterior_rollout(x, n_conditions, feats)
+            true_x = x[:, :n_conditions].transpose(0, 1).detach().cpu().clone()
+            predictions = torch.zeros((n_predictions, *x[:, 0].shape))
+            prediction = x[:, n_conditions - 1]
+            for i in range(n_predictions):
+                condition_list = self.extractor(prediction)
+                _, ht, ct = self.lstm(self._last(condition_list).unsqueeze(1), hprev, cprev)
+                pm, ps = self.prior(torch.cat((ht, zprev), dim=1))
+                zt = pm + ps * self.kl_temperature * torch.randn_like(pm)
+                hz = torch.cat((ht, zt), dim=1)
+                fc = self._flow_conditions(hz, condition_list)
+                prediction = self.flow.sample(None, fc, hz, temperature=self.temperature)
+                predictions[i] = prediction.detach().cpu()
+                hprev, cprev, zprev = ht, ct, zt
+        return true_x, predictions
+
+    def reconstruct(self, x):
+        """RFN/RFN_new.py:362-450 — posterior reconstructions and the flow bijection check g(f(x))."""
+        assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
+        with torch.no_grad():
+            T = x.shape[1]
+            hprev, cprev, aprev, caprev, _, zxprev, _, _, _ = self.get_inits()
+            recons = torch.zeros((T, *x[:, 0].shape))
+            recons_flow = torch.zeros((T, *x[:, 0].shape))
+            feats = [self.extractor(x[:, i]) for i in range(T)]
+            store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
+            for i in range(1, T):
+                ht = store_ht[i - 1]
+                if self.enable_smoothing:
+                    enc_mean, enc_std = self.encoder(torch.cat((store_at[i - 1], zxprev), dim=1))
+                else:
+                    enc_mean, enc_std = self.encoder(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
+                if self.res_q:
+                    prior_mean, _ = self.prior(torch.cat((ht, zxprev), dim=1))
+                    enc_mean = prior_mean + enc_mean
+                zxt = enc_mean + enc_std * torch.randn_like(enc_mean)
+                hz = torch.cat((ht, zxt), dim=1)
+                fc = self._flow_conditions(hz, feats[i - 1])
+                z, _ = self.flow.log_prob(x[:, i], fc, hz, 0.0)
+                recons_flow[i] = self.flow.sample(z, fc, hz, temperature=self.temperature).cpu()
+                recons[i] = self.flow.sample(None, fc, hz, temperature=self.temperature).cpu()
+                zxprev = zxt
+        return recons, recons_flow
+
+    def sample(self, x, n_samples):
+        """RFN/RFN_new.py:453-494 — unconditional roll-out from the first frame."""
+        assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
+        with torch.no_grad():
+            hprev, cprev, _, _, zprev, _, _, _, _ = self.get_inits()
+            samples = torch.zeros((n_samples, *x[:, 0].shape))
+            condition_list = self.extractor(x[:, 0])
+            for i in range(n_samples):
+                _, ht, ct = self.lstm(self._last(condition_list).unsqueeze(1), hprev, cprev)
+                pm, ps = self.prior(torch.cat((ht, zprev), dim=1))
+                zt = pm + ps * torch.randn_like(pm)
+                hz = torch.cat((ht, zt), dim=1)
+                fc = self._flow_conditions(hz, condition_list)
+                sample = self.flow.sample(None, fc, hz, temperature=self.temperature)
+                samples[i] = sample.cpu()
+                zprev, hprev, cprev = zt, ht, ct
+                condition_list = self.extractor(sample)
+        return samples

@@ -1,0 +1,287 @@
+"""Host-side modules with the reference's class names and state_dict keys (Utils/modules.py of the reference).
+
+* ConvLSTM / ConvLSTMLayer — ON the hot path: the cell runs on the gfx950 kernels (MFMA conv over cat(x,h) without
+  materialising the cat + fused gate update), see rfn_hip.ops.ConvLSTMCellFn.
+* VGG_downscaler / VGG_upscaler / SimpleParamNet / NormLayer / ActFun — callers of the hot path:
+  ordinary conv/BN stacks kept as PyTorch-ROCm modules, same constructor arguments and parameter names.
+"""
+import torch
+import torch.nn as nn
+
+from rfn_hip import ops as K
+
+
+class ActFun(nn.Module):
+    """Utils/modules.py:8-19."""
+
+    def __init__(self, non_lin, in_place=False):
+        super().__init__()
+        if non_lin == "relu":
+            self.net = nn.ReLU(inplace=in_place)
+        elif non_lin == "leakyrelu":
+            self.net = nn.LeakyReLU(negative_slope=0.20, inplace=in_place)
+        else:
+            assert False, "Please specify a activation type from the set {relu,leakyrelu}"
+        self.non_lin = non_lin
+
+    def forward(self, x):
+        return self.net(x)
+
+
+class NoNorm(nn.Module):
+    def forward(self, x):
+        return x
+
+
+class NormLayer(nn.Module):
+    """Utils/modules.py:28-41."""
+
+    def __init__(self, in_channels, norm_type):
+        super().__init__()
+        if norm_type == "batchnorm":
+            self.norm = nn.BatchNorm2d(in_channels)
+        elif norm_type == "instancenorm":
+            self.norm = nn.InstanceNorm2d(in_channels)
+        elif norm_type == "none":
+            self.norm = NoNorm()
+        else:
+            assert False, "Please specify a norm type from the set {batchnorm, instancenorm, none}"
+
+    def forward(self, x):
+        return self.norm(x)
+
+
+class Squeeze2dDecoder(nn.Module):
+    """Utils/modules.py:122-138 — space-to-depth inside the extractor/upscaler (same index map as Flow.Squeeze2d)."""
+
+    def __init__(self, undo_squeeze=False):
+        super().__init__()
+        self.undo_squeeze = undo_squeeze
+
+    def forward(self, x):
+        return K.Squeeze2dFn.apply(x.contiguous(), self.undo_squeeze)
+
+
+class tanh0_5(nn.Module):
+    def forward(self, x):
+        return 0.5 * torch.tanh(x)
+
+
+def _conv_block(cin, cout, norm_type, act, stride=1):
+    return [nn.Conv2d(cin, cout, kernel_size=3, stride=stride, padding=1, bias=False),
+            NormLayer(cout, norm_type=norm_type), act]
+
+
+class VGG_downscaler(nn.Module):
+    """Utils/modules.py:43-120 — L blocks; entries: int = conv3x3 to that width, 'pool', 'conv' (stride 2, x scale),
+    'squeeze'.  The last layer of the last block uses Tanh; `self.net` aliases the last block as in the reference."""
+
+    def __init__(self, structures, L, in_channels, norm_type="batchnorm", non_lin="relu", scale=2, skip_con=False,
+                 tanh=False):
+        super().__init__()
+        assert len(structures) == L, "Please specify number of blocks = L"
+        self.l_nets = nn.ModuleList([])
+        self.L, self.skip_con, self.scale = L, skip_con, scale
+        for l, structure in enumerate(structures):
+            layers = []
+            for count, item in enumerate(structure, 1):
+                last = count == len(structure)
+                if l == L - 1 and last:
+                    act = nn.Tanh()
+                elif last and tanh:
+                    act = tanh0_5()
+                else:
+                    act = ActFun(non_lin, in_place=True)
+                if item == "pool":
+                    layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+                elif item == "conv":
+                    cc = int(in_channels * scale)
+                    layers += _conv_block(in_channels, cc, norm_type, act, stride=2)
+                    in_channels = cc
+                elif item == "squeeze":
+                    cc = in_channels * 4
+                    layers += [Squeeze2dDecoder(undo_squeeze=False), NormLayer(cc, norm_type=norm_type), act]
+                    in_channels = cc
+                else:
+                    layers += _conv_block(in_channels, item, norm_type, act)
+                    in_channels = item
+            self.net = nn.Sequential(*layers)
+            self.l_nets.append(self.net)
+
+    def get_layer_size(self, structures, x_size):
+        bs, c, hx, wx = x_size
+        dims = []
+        for structure in structures:
+            for item in structure:
+                if item in ("pool", "conv", "squeeze"):
+                    hx, wx = hx // 2, wx // 2
+                    c = c if item == "pool" else (int(c * self.scale) if item == "conv" else c * 4)
+                else:
+                    c = item
+            dims.append([bs, c, hx, wx])
+        return dims
+
+    def forward(self, x, block_size=None):
+        outputs = []
+        for i in range(self.L):
+            x = self.l_nets[i](x)
+            if self.skip_con:
+                outputs.append(x)
+            else:
+                outputs = x
+        return outputs
+
+
+class VGG_upscaler(nn.Module):
+    """Utils/modules.py:147-214 — L blocks; block l>0 begins with an up-sampling stage kept in `upscales_nets[l-1]`;
+    with `skips` the matching extractor map is concatenated before the block's first conv."""
+
+    def __init__(self, structures, L, in_channels, norm_type="batchnorm", non_lin="relu", scale=2, skips=False,
+                 size_skips=None, tanh=False):
+        super().__init__()
+        assert len(structures) == L, "Please specify number of blocks = L"
+        self.l_nets = nn.ModuleList([])
+        self.upscales_nets = nn.ModuleList([])
+        self.L, self.skips = L, skips
+        size_skips.reverse()  # the reference mutates the caller's list too (Utils/modules.py:155)
+        for l, structure in enumerate(structures):
+            layers, layer_up = [], None
+            for count, item in enumerate(structure, 1):
+                last = count == len(structure)
+                act = tanh0_5() if (last and tanh) else ActFun(non_lin, in_place=True)
+                first_conv = (count == 1 and l == 0) or (count == 2 and l != 0)
+                skip_channels = size_skips[l][1] if (skips and first_conv) else 0
+                if item == "upsample":
+                    layer_up = [nn.Upsample(scale_factor=2, mode="nearest")]
+                elif item == "deconv":
+                    dc = in_channels // scale
+                    layer_up = [nn.ConvTranspose2d(in_channels, dc, kernel_size=4, stride=2, padding=1, bias=False),
+                                NormLayer(dc, norm_type=norm_type), act]
+                    in_channels = dc
+                elif item == "squeeze":
+                    dc = in_channels // 4
+                    layer_up = [Squeeze2dDecoder(undo_squeeze=True), NormLayer(dc, norm_type=norm_type), act]
+                    in_channels = dc
+                else:
+                    layers += [nn.Conv2d(in_channels + skip_channels, item, kernel_size=3, stride=1, padding=1,
+                                         bias=False), NormLayer(item, norm_type=norm_type), act]
+                    in_channels = item
+            if l > 0:
+                self.upscales_nets.append(nn.Sequential(*layer_up))
+            self.net = nn.Sequential(*layers)
+            self.l_nets.append(self.net)
+
+    def forward(self, x, skip_list=None):
+        outputs = []
+        rev = list(reversed(skip_list)) if self.skips else None
+        for i in range(self.L):
+            if i > 0:
+                x = self.upscales_nets[i - 1](x)
+            if self.skips:
+                x = self.l_nets[i](torch.cat((x, rev[i]), dim=1))
+            else:
+                x = self.l_nets[i](x)
+            outputs.append(x)
+        outputs.reverse()
+        return outputs
+
+
+class SimpleParamNet(nn.Module):
+    """Utils/modules.py:216-244 — conv stack then a conv producing (loc, softplus(raw scale))."""
+
+    def __init__(self, structure, in_channels, out_channels, norm_type="batchnorm", non_lin="leakyrelu", scale=2):
+        super().__init__()
+        layers = []
+        for item in structure:
+            if item == "pool":
+                layers.append(nn.MaxPool2d(kernel_size=2, stride=2))
+            elif item == "conv":
+                cc = int(scale * in_channels)
+                layers += [nn.Conv2d(in_channels, cc, kernel_size=3, stride=2, padding=1),
+                           NormLayer(cc, norm_type=norm_type), ActFun(non_lin, in_place=True)]
+                in_channels = cc
+            else:
+                layers += [nn.Conv2d(in_channels, item, kernel_size=3, padding=1), NormLayer(item, norm_type=norm_type),
+                           ActFun(non_lin, in_place=True)]
+                in_channels = item
+        self.net = nn.Sequential(*layers)
+        self.param_net = nn.Conv2d(in_channels, 2 * out_channels, kernel_size=3, stride=1, padding=1)
+        self.softplus = nn.Softplus()
+
+    def forward(self, x):
+        loc, log_scale = self.param_net(self.net(x)).chunk(2, 1)
+        return loc, self.softplus(log_scale)
+
+
+class ConvLSTMLayer(nn.Module):
+    """Utils/modules.py:326-393.  Parameters live in `self.conv[0]` (weight [4Hc, Cin+Hc, k, k], bias U(0,1), weights
+    xavier-normal).  The peephole tensors Wci/Wcf/Wco are created lazily as zeros like the reference does; they are
+    registered as (non-trained) parameters only so that reference CPU checkpoints, which contain them, load."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, bias, dropout=0, peephole=True, norm=False):
+        super().__init__()
+        assert not norm and dropout == 0, "GroupNorm / Dropout2d variants are not on the RFN path (defaults only)"
+        self.in_channels, self.hidden_channels = in_channels, hidden_channels
+        self.kernel_size, self.peephole, self.bias = kernel_size, peephole, bias
+        self.padding = ((kernel_size[0] - 1) // 2, (kernel_size[1] - 1) // 2)
+        assert kernel_size[0] == kernel_size[1] and kernel_size[0] in (1, 3), "kernels: 1x1 or 3x3"
+        self.conv = nn.Sequential(nn.Conv2d(in_channels + hidden_channels, 4 * hidden_channels, kernel_size, 1,
+                                            self.padding, bias=bias))
+        nn.init.xavier_normal_(self.conv[0].weight)
+        if bias:
+            nn.init.uniform_(self.conv[0].bias)
+        self.init_done = False
+        self._pe_nonzero = None
+
+    def initialize_peephole(self, height, width, device):
+        if self.peephole and not hasattr(self, "Wci"):
+            for n in ("Wci", "Wcf", "Wco"):
+                self.register_parameter(n, nn.Parameter(torch.zeros(1, self.hidden_channels, height, width,
+                                                                    device=device), requires_grad=False))
+
+    def _load_from_state_dict(self, state_dict, prefix, *args, **kw):
+        # reference CPU checkpoints carry lstm.LSTMlayer.{Wci,Wcf,Wco}; GPU ones do not
+        for n in ("Wci", "Wcf", "Wco"):
+            k = prefix + n
+            if k in state_dict and not hasattr(self, n):
+                self.register_parameter(n, nn.Parameter(torch.zeros_like(state_dict[k]), requires_grad=False))
+        self._pe_nonzero = None
+        super()._load_from_state_dict(state_dict, prefix, *args, **kw)
+
+    def forward(self, input_tensor, cur_state):
+        b, c, h, w = input_tensor.shape
+        conv = self.conv[0]
+        if cur_state[0] is None:
+            h_cur = torch.zeros(b, self.hidden_channels, h, w, device=input_tensor.device)
+            c_cur = torch.zeros(b, self.hidden_channels, h, w, device=input_tensor.device)
+        else:
+            h_cur, c_cur = cur_state
+        if not self.init_done:
+            self.initialize_peephole(h, w, input_tensor.device)
+            self.init_done = True
+        pe = [getattr(self, n, None) for n in ("Wci", "Wcf", "Wco")]
+        if pe[0] is not None:
+            if self._pe_nonzero is None:  # one host sync per (re)load, not per step; they are never trained
+                self._pe_nonzero = any(bool(t.any()) for t in pe)
+            if not self._pe_nonzero:
+                pe = [None, None, None]  # identically zero in every reference run: skip the reads
+        return K.ConvLSTMCellFn.apply(input_tensor.contiguous(), h_cur.contiguous(), c_cur.contiguous(), conv.weight,
+                                      conv.bias, pe[0], pe[1], pe[2])
+
+
+class ConvLSTM(nn.Module):
+    """Utils/modules.py:396-414 — x [B,S,C,H,W] -> (stack [B,S,Hc,H,W], h_S, c_S)."""
+
+    def __init__(self, in_channels, hidden_channels, kernel_size, bias=True, dropout=0, peephole=True, norm=False):
+        super().__init__()
+        self.hidden_channels = hidden_channels
+        self.LSTMlayer = ConvLSTMLayer(in_channels=in_channels, hidden_channels=hidden_channels,
+                                       kernel_size=kernel_size, bias=bias, dropout=dropout, peephole=peephole,
+                                       norm=norm)
+
+    def forward(self, x, ht=None, ct=None):
+        output = []
+        for t in range(x.size(1)):
+            ht, ct = self.LSTMlayer(input_tensor=x[:, t], cur_state=[ht, ct])
+            output.append(ht)
+        return torch.stack(output, 1), ht, ct

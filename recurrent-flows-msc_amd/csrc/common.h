@@ -1,0 +1,59 @@
+// Shared helpers for the gfx950 kernels of librfn_hip.so.  Wave = 64 lanes everywhere.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+
+#define RFN_WAVE 64
+
+extern "C" const char* rfn_last_error(void);
+void rfn_set_error(const char* fmt, ...);
+
+#define RFN_CHECK_ARG(cond, code)                                             \
+    do {                                                                      \
+        if (!(cond)) {                                                        \
+            rfn_set_error("%s: argument check failed: %s", __func__, #cond);  \
+            return (code);                                                    \
+        }                                                                     \
+    } while (0)
+
+#define RFN_LAUNCH_CHECK()                                                    \
+    do {                                                                      \
+        hipError_t e__ = hipGetLastError();                                   \
+        if (e__ != hipSuccess) {                                              \
+            rfn_set_error("%s: launch failed: %s", __func__, hipGetErrorString(e__)); \
+            return (int)e__;                                                  \
+        }                                                                     \
+    } while (0)
+
+// ---- wave / block reductions (sum) ---------------------------------------------------------------
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+
+// block-wide sum for blockDim.x == 256 (4 waves); result valid in every thread.
+__device__ __forceinline__ float block_sum_256(float v, float* sm /* >= 4 floats */) {
+    v = wave_sum(v);
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    __syncthreads();
+    if (lane == 0) sm[wave] = v;
+    __syncthreads();
+    return sm[0] + sm[1] + sm[2] + sm[3];
+}
+
+__device__ __forceinline__ float sigmoidf_(float x) { return 1.0f / (1.0f + __expf(-x)); }
+
+static inline int ceil_div(long a, long b) { return (int)((a + b - 1) / b); }
+static inline int next_pow2(int v) {
+    int p = 1;
+    while (p < v) p <<= 1;
+    return p;
+}
+static inline int ilog2(int v) {
+    int l = 0;
+    while ((1 << l) < v) ++l;
+    return l;
+}

@@ -1,0 +1,512 @@
+// Implicit-GEMM convolution (forward / data-gradient / weight-gradient) on the fp32 matrix cores of gfx950.
+//
+// Orientation (chosen for NCHW): D[cout][pixel] += W[cout][k] * X[k][pixel] with v_mfma_f32_32x32x2_f32, i.e.
+//   A operand (32 rows)  = weights      A[i = cout][k]      lane l holds (i = l&31, k = l>>5)
+//   B operand (32 cols)  = activations  B[k][j = pixel]     lane l holds (j = l&31, k = l>>5)
+//   D: col = lane&31 = pixel, row = (r&3) + 8*(r>>2) + 4*(lane>>5) = cout   -> a register's 32 lanes are 32
+//   consecutive pixels of one channel plane = one coalesced 128-byte store in NCHW.
+// A pixel tile is TF frames x TH rows x TWp cols (powers of two, TF*TH*TWp = BPX) so deep flow levels (2x2, 4x4
+// maps) fill a tile with many frames.  The input tile (with its 3x3 halo, zero filled outside the image) is staged
+// in LDS as [channel][frame][row+2][col+2]: a tap shift is a constant LDS offset and B-fragment reads are
+// lane-consecutive.  Weights are pre-packed (rfn_pack_conv_weight_f32) so that one 16-byte load per lane yields the
+// A fragments of four consecutive k-steps; they stream straight from L2 into registers, prefetched one iteration ahead.
+#include "common.h"
+#include "../../include/rfn_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct ConvParams {
+    const float* in1;
+    const float* in2;
+    long in1_ns, in2_ns;
+    int C1, C2;
+    const float* wpk;
+    float* out1;
+    float* out2;
+    long out1_ns, out2_ns;
+    int Cout, cout_split, acc1, acc2;
+    int N, H, W;
+    int CoutP, Cin8;
+    int ep_mode, act;
+    const float* p0;
+    const float* p1;
+    int TWp, TH, TF, tw_shift, th_shift;
+    int n_wtiles, n_htiles, n_ftiles;
+};
+
+// packed weight index: (((g8*T + tap)*2 + kk)*CoutP + co)*4 + ks   <->  cin = g8*8 + 2*ks + kk
+__global__ void pack_weight_kernel(const float* __restrict__ w, float* __restrict__ wpk, int Cout, int Cin, int KS,
+                                   int CoutP, int Cin8, int transpose_flip) {
+    // logical conv described by the packed buffer: Co_l outputs, Ci_l inputs
+    const int T = KS * KS;
+    const int Co_l = transpose_flip ? Cin : Cout;
+    const int Ci_l = transpose_flip ? Cout : Cin;
+    const long total = (long)Cin8 * T * 2 * CoutP * 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int ks = (int)(idx & 3);
+        long r = idx >> 2;
+        int co = (int)(r % CoutP);
+        r /= CoutP;
+        int kk = (int)(r & 1);
+        r >>= 1;
+        int tap = (int)(r % T);
+        int g8 = (int)(r / T);
+        int ci = g8 * 8 + 2 * ks + kk;
+        float v = 0.f;
+        if (co < Co_l && ci < Ci_l) {
+            if (!transpose_flip)
+                v = w[((long)co * Cin + ci) * T + tap];
+            else
+                v = w[((long)ci * Cin + co) * T + (T - 1 - tap)];  // w[cout=ci_l][cin=co_l][mirrored tap]
+        }
+        wpk[idx] = v;
+    }
+}
+
+// CoutP is padded to the cout block of the kernel configuration chosen for this Cout (see rfn_conv2d_fwd_f32), so
+// every A-fragment load of a launched block stays inside the packed buffer.
+static inline void packed_dims(int Cout_l, int Cin_l, int* CoutP, int* Cin8) {
+    *CoutP = Cout_l <= 32 ? 32 : (Cout_l <= 64 ? 64 : ((Cout_l + 127) / 128) * 128);
+    *Cin8 = (Cin_l + 7) / 8;
+}
+
+extern "C" long rfn_packed_weight_size(int Cout, int Cin, int ks) {
+    // large enough for both orientations
+    int a, b, c, d;
+    packed_dims(Cout, Cin, &a, &b);
+    packed_dims(Cin, Cout, &c, &d);
+    long s0 = (long)b * ks * ks * 2 * a * 4, s1 = (long)d * ks * ks * 2 * c * 4;
+    return s0 > s1 ? s0 : s1;
+}
+
+extern "C" int rfn_pack_conv_weight_f32(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
+                                        rfn_stream_t stream) {
+    RFN_CHECK_ARG(w && wpk && Cout > 0 && Cin > 0 && (ks == 1 || ks == 3), -1);
+    int CoutP, Cin8;
+    if (!transpose_flip)
+        packed_dims(Cout, Cin, &CoutP, &Cin8);
+    else
+        packed_dims(Cin, Cout, &CoutP, &Cin8);
+    long total = (long)Cin8 * ks * ks * 2 * CoutP * 4;
+    int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, wpk, Cout, Cin, ks, CoutP,
+                       Cin8, transpose_flip);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ forward / dgrad
+template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
+__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2;
+    constexpr int BCO = 32 * TCO * WCO;
+    static_assert(WCO * WPX == 4, "4 waves");
+    extern __shared__ float lds[];  // [KC][IMG]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave / WPX, wpx = wave % WPX;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int HW = p.H * p.W;
+    const int Cin = p.C1 + p.C2;
+
+    int pt = blockIdx.x;
+    const int wt = pt % p.n_wtiles;
+    pt /= p.n_wtiles;
+    const int ht = pt % p.n_htiles;
+    const int ft = pt / p.n_htiles;
+    const int x0 = wt * p.TWp, y0 = ht * p.TH, f0 = ft * p.TF;
+    const int RW = p.TWp + 2 * PAD, RH = p.TH + 2 * PAD;
+    const int FRM = RH * RW;       // one frame's padded image
+    const int IMG = p.TF * FRM;    // per channel
+    const int co_base = blockIdx.y * BCO + wco * (32 * TCO);
+
+    int lds_off[TPX], pn[TPX], ppix[TPX];
+    bool pvalid[TPX];
+#pragma unroll
+    for (int t = 0; t < TPX; ++t) {
+        int q = (wpx * TPX + t) * 32 + l31;
+        int col = q & (p.TWp - 1);
+        int row = (q >> p.tw_shift) & (p.TH - 1);
+        int f = q >> (p.tw_shift + p.th_shift);
+        lds_off[t] = f * FRM + row * RW + col;
+        pvalid[t] = (x0 + col < p.W) && (y0 + row < p.H) && (f0 + f < p.N);
+        pn[t] = f0 + f;
+        ppix[t] = (y0 + row) * p.W + x0 + col;
+    }
+
+    f32x16 acc[TCO][TPX];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a)
+#pragma unroll
+        for (int t = 0; t < TPX; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    const int total_it = p.Cin8 * T;
+    const f32x4* wp4 = reinterpret_cast<const f32x4*>(p.wpk);
+    // A fragment of iteration `it` for cout tile a:  wp4[(it*2 + kk)*CoutP + co_base + a*32 + l31]
+    f32x4 a_cur[TCO], a_nxt[TCO];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) a_cur[a] = wp4[((long)0 * 2 + kk) * p.CoutP + co_base + a * 32 + l31];
+
+    const int nchunks = (p.Cin8 * 8 + KC - 1) / KC;
+    for (int chunk = 0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        // ---- stage KC channels of the haloed tile (zero outside the image / past Cin / past N)
+        const int cb = chunk * KC;
+        for (int idx = tid; idx < KC * IMG; idx += 256) {
+            int c = idx / IMG;
+            int r = idx - c * IMG;
+            int f = r / FRM;
+            int rr = r - f * FRM;
+            int yy = rr / RW;
+            int xx = rr - yy * RW;
+            int gy = y0 + yy - PAD, gx = x0 + xx - PAD, n = f0 + f, ch = cb + c;
+            float v = 0.f;
+            if (ch < Cin && n < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                if (ch < p.C1)
+                    v = p.in1[n * p.in1_ns + (long)ch * HW + gy * p.W + gx];
+                else
+                    v = p.in2[n * p.in2_ns + (long)(ch - p.C1) * HW + gy * p.W + gx];
+            }
+            lds[idx] = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s8 = 0; s8 < KC / 8; ++s8) {
+            const int g8 = chunk * (KC / 8) + s8;
+            if (g8 >= p.Cin8) break;
+            int nks = (Cin - g8 * 8 + 1) >> 1;
+            nks = nks > 4 ? 4 : nks;
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                const int it = g8 * T + tap;
+                if (it + 1 < total_it) {
+#pragma unroll
+                    for (int a = 0; a < TCO; ++a)
+                        a_nxt[a] = wp4[((long)(it + 1) * 2 + kk) * p.CoutP + co_base + a * 32 + l31];
+                }
+                const int tapoff = (tap / KS) * RW + (tap % KS);
+#pragma unroll
+                for (int ks = 0; ks < 4; ++ks) {
+                    if (ks < nks) {
+                        const float* lrow = lds + (s8 * 8 + 2 * ks + kk) * IMG + tapoff;
+                        float b[TPX];
+#pragma unroll
+                        for (int t = 0; t < TPX; ++t) b[t] = lrow[lds_off[t]];
+#pragma unroll
+                        for (int a = 0; a < TCO; ++a)
+#pragma unroll
+                            for (int t = 0; t < TPX; ++t)
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][ks], b[t], acc[a][t], 0, 0, 0);
+                    }
+                }
+#pragma unroll
+                for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
+            }
+        }
+    }
+
+    // ---- epilogue
+#pragma unroll
+    for (int a = 0; a < TCO; ++a) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int co = co_base + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            if (co >= p.Cout) continue;
+            float e0 = 0.f, e1 = 1.f;
+            if (p.ep_mode == 1) {
+                e0 = p.p0[co];
+                e1 = expf(p.p1[co]);
+            } else if (p.ep_mode == 2) {
+                e0 = p.p0[co];
+                e1 = expf(3.f * p.p1[co]);
+            } else if (p.ep_mode == 3) {
+                e0 = p.p0[co];
+            }
+            const bool first = co < p.cout_split;
+            float* obase = first ? p.out1 : p.out2;
+            const long ons = first ? p.out1_ns : p.out2_ns;
+            const int oc = first ? co : co - p.cout_split;
+            const int accm = first ? p.acc1 : p.acc2;
+#pragma unroll
+            for (int t = 0; t < TPX; ++t) {
+                if (!pvalid[t]) continue;
+                float v = acc[a][t][r];
+                if (p.ep_mode != 0) v = (v + e0) * e1;
+                if (p.ep_mode == 1) {
+                    if (p.act == 1) v = v > 0.f ? v : 0.f;
+                    if (p.act == 2) v = v > 0.f ? v : 0.2f * v;
+                }
+                float* dst = obase + pn[t] * ons + (long)oc * HW + ppix[t];
+                if (accm) v += *dst;
+                *dst = v;
+            }
+        }
+    }
+}
+
+static void tile_geometry(int H, int W, int BPX, int* TWp, int* TH, int* TF) {
+    int tw = next_pow2(W);
+    if (tw > 32) tw = 32;
+    if (tw > BPX) tw = BPX;
+    int th = next_pow2(H);
+    if (th > BPX / tw) th = BPX / tw;
+    *TWp = tw;
+    *TH = th;
+    *TF = BPX / (tw * th);
+}
+
+template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
+static int launch_conv(ConvParams& p, hipStream_t s) {
+    constexpr int BCO = 32 * TCO * WCO, BPX = 32 * TPX * WPX, PAD = KS / 2;
+    tile_geometry(p.H, p.W, BPX, &p.TWp, &p.TH, &p.TF);
+    p.tw_shift = ilog2(p.TWp);
+    p.th_shift = ilog2(p.TH);
+    p.n_wtiles = ceil_div(p.W, p.TWp);
+    p.n_htiles = ceil_div(p.H, p.TH);
+    p.n_ftiles = ceil_div(p.N, p.TF);
+    size_t lds = (size_t)KC * p.TF * (p.TH + 2 * PAD) * (p.TWp + 2 * PAD) * 4;
+    auto kern = conv_mfma_kernel<KS, WCO, WPX, TCO, TPX, KC>;
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(p.n_wtiles * p.n_htiles * p.n_ftiles, ceil_div(p.Cout, BCO));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return 0;
+}
+
+extern "C" int rfn_conv2d_fwd_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                                  const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                                  int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
+                                  const float* p0, const float* p1, int act, rfn_stream_t stream) {
+    RFN_CHECK_ARG(in1 && wpk && out1 && C1 > 0 && C2 >= 0 && Cout > 0 && N >= 0 && H > 0 && W > 0, -1);
+    RFN_CHECK_ARG(ks == 1 || ks == 3, -2);
+    RFN_CHECK_ARG(C2 == 0 || in2, -3);
+    RFN_CHECK_ARG(cout_split >= 0 && cout_split <= Cout && (cout_split == Cout || out2), -4);
+    RFN_CHECK_ARG(ep_mode >= 0 && ep_mode <= 3 && (ep_mode == 0 || p0) && ((ep_mode != 1 && ep_mode != 2) || p1), -5);
+    RFN_CHECK_ARG(((uintptr_t)wpk & 15) == 0, -6);
+    if (N == 0) return 0;
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.in1 = in1; p.in2 = in2; p.in1_ns = in1_ns; p.in2_ns = in2_ns; p.C1 = C1; p.C2 = C2;
+    p.wpk = wpk; p.out1 = out1; p.out2 = out2; p.out1_ns = out1_ns; p.out2_ns = out2_ns;
+    p.Cout = Cout; p.cout_split = cout_split; p.acc1 = acc1; p.acc2 = acc2;
+    p.N = N; p.H = H; p.W = W;
+    packed_dims(Cout, C1 + C2, &p.CoutP, &p.Cin8);
+    p.ep_mode = ep_mode; p.act = act; p.p0 = p0; p.p1 = p1;
+    hipStream_t s = (hipStream_t)stream;
+    if (ks == 3) {
+        if (Cout <= 32)
+            launch_conv<3, 1, 4, 1, 2, 8>(p, s);
+        else if (Cout <= 64)
+            launch_conv<3, 1, 4, 2, 1, 8>(p, s);
+        else
+            launch_conv<3, 2, 2, 2, 2, 8>(p, s);
+    } else {
+        if (Cout <= 32)
+            launch_conv<1, 1, 4, 1, 2, 32>(p, s);
+        else if (Cout <= 64)
+            launch_conv<1, 1, 4, 2, 1, 32>(p, s);
+        else
+            launch_conv<1, 2, 2, 2, 2, 32>(p, s);
+    }
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ weight gradient
+// gwt[tap][co][ci] += Σ_pixels g[co][px] * x[ci][px + tap]      (tap-major so the final float atomics of one
+// register are 32 consecutive floats = full-rate 128-byte atomic segments).
+struct WgradParams {
+    const float* in1;
+    const float* in2;
+    long in1_ns, in2_ns;
+    int C1, C2;
+    const float* g;
+    long g_ns;
+    int Cout;
+    float* gwt;
+    int N, H, W;
+    int TWp, TH, TF, tw_shift, th_shift;
+    int n_wtiles, n_htiles, n_ftiles, n_pix_tiles;
+};
+
+template <int KS, int WCO, int WCI, int TCO, int TCI, int BPX>
+__global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2;
+    constexpr int BCO = 32 * TCO * WCO, BCI = 32 * TCI * WCI;
+    constexpr int GSTR = BPX + 1;
+    static_assert(WCO * WCI == 4, "4 waves");
+    extern __shared__ float lds[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave / WCI, wci = wave % WCI;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int HW = p.H * p.W, Cin = p.C1 + p.C2;
+    const int RW = p.TWp + 2 * PAD, RH = p.TH + 2 * PAD, FRM = RH * RW, IMG = p.TF * FRM;
+    const int XSTR = IMG | 1;
+    float* Gs = lds;               // [BCO][GSTR]
+    float* Xs = lds + BCO * GSTR;  // [BCI][XSTR]
+    const int co0 = blockIdx.z * BCO, ci0 = blockIdx.y * BCI;
+
+    f32x16 acc[TCO][TCI][T];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a)
+#pragma unroll
+        for (int b = 0; b < TCI; ++b)
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[a][b][t][r] = 0.f;
+
+    for (int ptile = blockIdx.x; ptile < p.n_pix_tiles; ptile += gridDim.x) {
+        int pt = ptile;
+        const int wt = pt % p.n_wtiles;
+        pt /= p.n_wtiles;
+        const int ht = pt % p.n_htiles;
+        const int ft = pt / p.n_htiles;
+        const int x0 = wt * p.TWp, y0 = ht * p.TH, f0 = ft * p.TF;
+        __syncthreads();
+        for (int idx = tid; idx < BCO * BPX; idx += 256) {
+            int cl = idx / BPX, q = idx - cl * BPX;
+            int col = q & (p.TWp - 1), row = (q >> p.tw_shift) & (p.TH - 1), f = q >> (p.tw_shift + p.th_shift);
+            int co = co0 + cl, n = f0 + f, gy = y0 + row, gx = x0 + col;
+            float v = 0.f;
+            if (co < p.Cout && n < p.N && gy < p.H && gx < p.W) v = p.g[n * p.g_ns + (long)co * HW + gy * p.W + gx];
+            Gs[cl * GSTR + q] = v;
+        }
+        for (int idx = tid; idx < BCI * IMG; idx += 256) {
+            int cl = idx / IMG, r = idx - cl * IMG;
+            int f = r / FRM, rr = r - f * FRM, yy = rr / RW, xx = rr - yy * RW;
+            int gy = y0 + yy - PAD, gx = x0 + xx - PAD, n = f0 + f, ch = ci0 + cl;
+            float v = 0.f;
+            if (ch < Cin && n < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
+                if (ch < p.C1)
+                    v = p.in1[n * p.in1_ns + (long)ch * HW + gy * p.W + gx];
+                else
+                    v = p.in2[n * p.in2_ns + (long)(ch - p.C1) * HW + gy * p.W + gx];
+            }
+            Xs[cl * XSTR + r] = v;
+        }
+        __syncthreads();
+        const float* ga = Gs + (wco * TCO * 32 + l31) * GSTR;
+        const float* xb = Xs + (wci * TCI * 32 + l31) * XSTR;
+        for (int k2 = 0; k2 < BPX / 2; ++k2) {
+            const int q = 2 * k2 + kk;
+            const int col = q & (p.TWp - 1), row = (q >> p.tw_shift) & (p.TH - 1), f = q >> (p.tw_shift + p.th_shift);
+            const int ioff = f * FRM + row * RW + col;
+            float av[TCO];
+#pragma unroll
+            for (int a = 0; a < TCO; ++a) av[a] = ga[a * 32 * GSTR + q];
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int tapoff = (t / KS) * RW + (t % KS);
+                float bv[TCI];
+#pragma unroll
+                for (int b = 0; b < TCI; ++b) bv[b] = xb[b * 32 * XSTR + ioff + tapoff];
+#pragma unroll
+                for (int a = 0; a < TCO; ++a)
+#pragma unroll
+                    for (int b = 0; b < TCI; ++b)
+                        acc[a][b][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(av[a], bv[b], acc[a][b][t], 0, 0, 0);
+            }
+        }
+    }
+    // D[i = co][j = ci]: col = lane&31 = ci, row = (r&3)+8*(r>>2)+4*kk = co
+#pragma unroll
+    for (int a = 0; a < TCO; ++a)
+#pragma unroll
+        for (int b = 0; b < TCI; ++b) {
+            const int ci = ci0 + (wci * TCI + b) * 32 + l31;
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int co = co0 + (wco * TCO + a) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                    if (co < p.Cout && ci < Cin) atomicAdd(&p.gwt[((long)t * p.Cout + co) * Cin + ci], acc[a][b][t][r]);
+                }
+        }
+}
+
+template <int KS, int WCO, int WCI, int TCO, int TCI, int BPX>
+static void launch_wgrad_bpx(WgradParams& p, hipStream_t s) {
+    constexpr int BCO = 32 * TCO * WCO, BCI = 32 * TCI * WCI, PAD = KS / 2;
+    tile_geometry(p.H, p.W, BPX, &p.TWp, &p.TH, &p.TF);
+    p.tw_shift = ilog2(p.TWp);
+    p.th_shift = ilog2(p.TH);
+    p.n_wtiles = ceil_div(p.W, p.TWp);
+    p.n_htiles = ceil_div(p.H, p.TH);
+    p.n_ftiles = ceil_div(p.N, p.TF);
+    p.n_pix_tiles = p.n_wtiles * p.n_htiles * p.n_ftiles;
+    int IMG = p.TF * (p.TH + 2 * PAD) * (p.TWp + 2 * PAD);
+    size_t lds = ((size_t)BCO * (BPX + 1) + (size_t)BCI * (IMG | 1)) * 4;
+    int tiles = ceil_div(p.Cout, BCO) * ceil_div(p.C1 + p.C2, BCI);
+    int S = 1024 / tiles;
+    if (S < 1) S = 1;
+    if (S > p.n_pix_tiles) S = p.n_pix_tiles;
+    auto kern = wgrad_mfma_kernel<KS, WCO, WCI, TCO, TCI, BPX>;
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(S, ceil_div(p.C1 + p.C2, BCI), ceil_div(p.Cout, BCO));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+}
+
+// tiny maps (<= 4x4) use 64-pixel tiles: their zero-padded LDS image is 2.25-4x the tile, and 128 would not fit.
+template <int KS, int WCO, int WCI, int TCO, int TCI>
+static void launch_wgrad(WgradParams& p, hipStream_t s) {
+    if (p.H * p.W <= 16)
+        launch_wgrad_bpx<KS, WCO, WCI, TCO, TCI, 64>(p, s);
+    else
+        launch_wgrad_bpx<KS, WCO, WCI, TCO, TCI, 128>(p, s);
+}
+
+extern "C" int rfn_conv2d_wgrad_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                                    const float* g, long g_ns, int Cout, float* gwt, int N, int H, int W, int ks,
+                                    rfn_stream_t stream) {
+    RFN_CHECK_ARG(in1 && g && gwt && C1 > 0 && C2 >= 0 && Cout > 0 && N >= 0 && H > 0 && W > 0, -1);
+    RFN_CHECK_ARG(ks == 1 || ks == 3, -2);
+    RFN_CHECK_ARG(C2 == 0 || in2, -3);
+    if (N == 0) return 0;
+    WgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.in1 = in1; p.in2 = in2; p.in1_ns = in1_ns; p.in2_ns = in2_ns; p.C1 = C1; p.C2 = C2;
+    p.g = g; p.g_ns = g_ns; p.Cout = Cout; p.gwt = gwt; p.N = N; p.H = H; p.W = W;
+    hipStream_t s = (hipStream_t)stream;
+    const int Cin = C1 + C2;
+    if (ks == 3) {
+        if (Cin <= 32)
+            launch_wgrad<3, 4, 1, 1, 1>(p, s);   // 128 co x 32 ci
+        else if (Cout <= 32)
+            launch_wgrad<3, 1, 4, 1, 1>(p, s);   // 32 co x 128 ci
+        else
+            launch_wgrad<3, 2, 2, 1, 1>(p, s);   // 64 x 64
+    } else {
+        if (Cin <= 32)
+            launch_wgrad<1, 4, 1, 2, 1>(p, s);   // 256 co x 32 ci
+        else if (Cout <= 32)
+            launch_wgrad<1, 1, 4, 1, 2>(p, s);   // 32 co x 256 ci
+        else
+            launch_wgrad<1, 2, 2, 2, 2>(p, s);   // 128 x 128
+    }
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// gw[co][ci][tap] (+)= gwt[tap][co][ci]
+__global__ void wgrad_finish_kernel(const float* __restrict__ gwt, float* __restrict__ gw, int Cout, int Cin, int T,
+                                    int accumulate) {
+    const long total = (long)Cout * Cin * T;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int t = (int)(idx % T);
+        long r = idx / T;  // co*Cin + ci
+        float v = gwt[(long)t * Cout * Cin + r];
+        gw[idx] = accumulate ? gw[idx] + v : v;
+    }
+}
+extern "C" int rfn_wgrad_finish_f32(const float* gwt, float* gw, int Cout, int Cin, int ks, int accumulate,
+                                    rfn_stream_t stream) {
+    RFN_CHECK_ARG(gwt && gw && Cout > 0 && Cin > 0 && (ks == 1 || ks == 3), -1);
+    long total = (long)Cout * Cin * ks * ks;
+    int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(wgrad_finish_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gwt, gw, Cout, Cin, ks * ks,
+                       accumulate);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}

@@ -1,0 +1,685 @@
+// HBM-bound "shell" kernels of the Glow step and the ConvLSTM gate update (gfx950).
+// Everything here is a streaming pass: coalesced NCHW loads along the pixel dimension (consecutive lanes =
+// consecutive pixels), per-frame / per-channel reductions done with wave shuffles + one LDS hop, never a GEMM.
+#include "common.h"
+#include "../../include/rfn_hip.h"
+#include <stdarg.h>
+
+static thread_local char g_err[512] = "";
+void rfn_set_error(const char* fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof(g_err), fmt, ap);
+    va_end(ap);
+}
+extern "C" const char* rfn_last_error(void) { return g_err; }
+extern "C" int rfn_abi_version(void) { return 1; }
+
+// ------------------------------------------------------------------------------------------------ squeeze2d
+// forward: each thread reads one float2 (input row 2h+i, cols 2w,2w+1) and writes the two output planes j=0,1.
+__global__ void squeeze2d_fwd_kernel(const float* __restrict__ x, long x_ns, float* __restrict__ y, long y_ns, int N,
+                                     int C, int H, int W) {
+    const int W2 = W >> 1, H2 = H >> 1;
+    const long total = (long)N * C * H * W2;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int w = (int)(idx % W2);
+        long r = idx / W2;
+        int hin = (int)(r % H);
+        r /= H;
+        int c = (int)(r % C);
+        int n = (int)(r / C);
+        const float* src = x + n * x_ns + ((long)c * H + hin) * W + 2 * w;
+        float v0 = src[0], v1 = src[1];
+        int i = hin & 1, h = hin >> 1;
+        float* dst = y + n * y_ns + ((long)(4 * c + 2 * i) * H2 + h) * W2 + w;
+        dst[0] = v0;
+        dst[(long)H2 * W2] = v1;
+    }
+}
+// undo: C,H,W are the INPUT dims (C multiple of 4); output is [C/4, 2H, 2W].
+__global__ void squeeze2d_undo_kernel(const float* __restrict__ x, long x_ns, float* __restrict__ y, long y_ns, int N,
+                                      int C, int H, int W) {
+    const int Co = C >> 2, Ho = H * 2, Wo = W * 2;
+    const long total = (long)N * Co * Ho * W;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        int w = (int)(idx % W);
+        long r = idx / W;
+        int hout = (int)(r % Ho);
+        r /= Ho;
+        int c = (int)(r % Co);
+        int n = (int)(r / Co);
+        int i = hout & 1, h = hout >> 1;
+        const float* src = x + n * x_ns + ((long)(4 * c + 2 * i) * H + h) * W + w;
+        float v0 = src[0], v1 = src[(long)H * W];
+        float* dst = y + n * y_ns + ((long)c * Ho + hout) * Wo + 2 * w;
+        dst[0] = v0;
+        dst[1] = v1;
+    }
+}
+
+extern "C" int rfn_squeeze2d_f32(const float* x, long x_ns, float* y, long y_ns, int N, int C, int H, int W, int undo,
+                                 rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && y && N >= 0 && C > 0 && H > 0 && W > 0, -1);
+    if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    if (!undo) {
+        RFN_CHECK_ARG((H % 2 == 0) && (W % 2 == 0), -2);
+        long total = (long)N * C * H * (W / 2);
+        int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(squeeze2d_fwd_kernel, dim3(grid), dim3(256), 0, s, x, x_ns, y, y_ns, N, C, H, W);
+    } else {
+        RFN_CHECK_ARG(C % 4 == 0, -2);
+        long total = (long)N * (C / 4) * (H * 2) * W;
+        int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+        hipLaunchKernelGGL(squeeze2d_undo_kernel, dim3(grid), dim3(256), 0, s, x, x_ns, y, y_ns, N, C, H, W);
+    }
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ channel stats
+// One block per channel: pass 1 mean, pass 2 Σ(x-mean)² / (n-1)   (ActNorm data dependent init; one-time cost).
+__global__ __launch_bounds__(256) void channel_stats_kernel(const float* __restrict__ x, long x_ns, float* mean,
+                                                            float* var, int N, int C, int HW) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x;
+    const long cnt = (long)N * HW;
+    float s = 0.f;
+    for (long i = threadIdx.x; i < cnt; i += 256) {
+        int n = (int)(i / HW), p = (int)(i % HW);
+        s += x[n * x_ns + (long)c * HW + p];
+    }
+    float m = block_sum_256(s, sm) / (float)cnt;
+    float q = 0.f;
+    for (long i = threadIdx.x; i < cnt; i += 256) {
+        int n = (int)(i / HW), p = (int)(i % HW);
+        float d = x[n * x_ns + (long)c * HW + p] - m;
+        q += d * d;
+    }
+    q = block_sum_256(q, sm);
+    if (threadIdx.x == 0) {
+        mean[c] = m;
+        var[c] = q / (float)(cnt - 1);
+    }
+}
+extern "C" int rfn_channel_stats_f32(const float* x, long x_ns, float* mean, float* var_unbiased, int N, int C, int HW,
+                                     rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && mean && var_unbiased && N > 0 && C > 0 && HW > 0, -1);
+    hipLaunchKernelGGL(channel_stats_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, x_ns, mean, var_unbiased, N,
+                       C, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ actnorm + invconv
+// A block owns PB consecutive "global pixels" q = n*HW + p.  y = (x+b)*exp(l) is staged in LDS as [C][PB]
+// (lane-consecutive pixels -> conflict free); every thread then forms the C outputs of its pixel with W read through
+// the scalar cache (uniform indices).
+template <int REV>
+__global__ __launch_bounds__(256) void actnorm_invconv_kernel(const float* __restrict__ x, long x_ns,
+                                                              const float* __restrict__ bias,
+                                                              const float* __restrict__ logs,
+                                                              const float* __restrict__ Wm, float* __restrict__ z,
+                                                              long z_ns, int N, int C, int HW, int PB) {
+    extern __shared__ float lds[];  // [C][PB]
+    const long q = (long)blockIdx.x * PB + threadIdx.x;
+    const bool valid = threadIdx.x < PB && q < (long)N * HW;
+    int n = 0, p = 0;
+    if (valid) {
+        n = (int)(q / HW);
+        p = (int)(q % HW);
+    }
+    if (valid) {
+        const float* src = x + n * x_ns + p;
+        for (int c = 0; c < C; ++c) {
+            float v = src[(long)c * HW];
+            if (!REV) v = (v + bias[c]) * expf(logs[c]);
+            lds[c * PB + threadIdx.x] = v;
+        }
+        float* dst = z + n * z_ns + p;
+        for (int i = 0; i < C; ++i) {
+            float a = 0.f;
+            const float* wr = Wm + (long)i * C;
+            for (int j = 0; j < C; ++j) a = fmaf(wr[j], lds[j * PB + threadIdx.x], a);
+            if (REV) a = a * expf(-logs[i]) - bias[i];
+            dst[(long)i * HW] = a;
+        }
+    }
+}
+
+static int shell_pb(int C) {
+    int PB = 256;
+    while ((long)C * PB * 4 > 49152 && PB > 64) PB >>= 1;
+    return PB;
+}
+
+static int launch_actnorm_invconv(int rev, const float* x, long x_ns, const float* bias, const float* logs,
+                                  const float* Wm, float* z, long z_ns, int N, int C, int HW, hipStream_t s) {
+    int PB = shell_pb(C);
+    size_t lds = (size_t)C * PB * 4;
+    if (lds > 160 * 1024) {
+        rfn_set_error("actnorm_invconv: C=%d too large for the LDS-staged kernel", C);
+        return -3;
+    }
+    long tot = (long)N * HW;
+    int grid = (int)((tot + PB - 1) / PB);
+    if (rev) {
+        if (lds > 65536)
+            (void)hipFuncSetAttribute((const void*)actnorm_invconv_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        hipLaunchKernelGGL(actnorm_invconv_kernel<1>, dim3(grid), dim3(256), lds, s, x, x_ns, bias, logs, Wm, z, z_ns, N,
+                           C, HW, PB);
+    } else {
+        if (lds > 65536)
+            (void)hipFuncSetAttribute((const void*)actnorm_invconv_kernel<0>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)lds);
+        hipLaunchKernelGGL(actnorm_invconv_kernel<0>, dim3(grid), dim3(256), lds, s, x, x_ns, bias, logs, Wm, z, z_ns, N,
+                           C, HW, PB);
+    }
+    return 0;
+}
+
+extern "C" int rfn_actnorm_invconv_fwd_f32(const float* x, long x_ns, const float* bias, const float* logs,
+                                           const float* Wm, float* z, long z_ns, int N, int C, int HW,
+                                           rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && bias && logs && Wm && z && N >= 0 && C > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    int rc = launch_actnorm_invconv(0, x, x_ns, bias, logs, Wm, z, z_ns, N, C, HW, (hipStream_t)stream);
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int rfn_invconv_actnorm_rev_f32(const float* zin, long z_ns, const float* bias, const float* logs,
+                                           const float* Winv, float* x, long x_ns, int N, int C, int HW,
+                                           rfn_stream_t stream) {
+    RFN_CHECK_ARG(zin && bias && logs && Winv && x && N >= 0 && C > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    int rc = launch_actnorm_invconv(1, zin, z_ns, bias, logs, Winv, x, x_ns, N, C, HW, (hipStream_t)stream);
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward.  LDS: Y[C][PBS] and G[C][PBS] with PBS = PB+1 (odd stride: the gW phase reads rows with a stride).
+__global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
+    const float* __restrict__ x, long x_ns, const float* __restrict__ bias, const float* __restrict__ logs,
+    const float* __restrict__ Wm, const float* __restrict__ gz, long gz_ns, float* __restrict__ gx, long gx_ns,
+    float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ glogs, int N, int C, int HW, int PB) {
+    extern __shared__ float lds[];
+    const int PBS = PB + 1;
+    float* Y = lds;            // [C][PBS]  y, later gy*y
+    float* G = lds + C * PBS;  // [C][PBS]  gz, later gy*exp(logs)
+    const int t = threadIdx.x;
+    const long q = (long)blockIdx.x * PB + t;
+    const bool valid = t < PB && q < (long)N * HW;
+    int n = 0, p = 0;
+    if (valid) {
+        n = (int)(q / HW);
+        p = (int)(q % HW);
+    }
+    if (t < PB) {
+        for (int c = 0; c < C; ++c) {
+            float yv = 0.f, gv = 0.f;
+            if (valid) {
+                yv = (x[n * x_ns + (long)c * HW + p] + bias[c]) * expf(logs[c]);
+                gv = gz[n * gz_ns + (long)c * HW + p];
+            }
+            Y[c * PBS + t] = yv;
+            G[c * PBS + t] = gv;
+        }
+    }
+    __syncthreads();
+    // gW[i][j] += Σ_p gz_i(p) y_j(p)
+    for (int e = t; e < C * C; e += 256) {
+        int i = e / C, j = e % C;
+        const float* gi = G + i * PBS;
+        const float* yj = Y + j * PBS;
+        float a = 0.f;
+        for (int pp = 0; pp < PB; ++pp) a = fmaf(gi[pp], yj[pp], a);
+        atomicAdd(&gW[e], a);
+    }
+    __syncthreads();
+    // gy_j = Σ_i W[i][j] gz_i ; gx_j = gy_j * exp(logs_j) ; gbias_j += Σ gx_j ; glogs_j += Σ gy_j y_j.
+    // PB is a multiple of 64, so whole waves are in or out of this branch and wave_sum sees all 64 lanes;
+    // pixels past the end were staged as zeros and contribute nothing.
+    if (t < PB) {
+        for (int j = 0; j < C; ++j) {
+            float a = 0.f;
+            for (int i = 0; i < C; ++i) a = fmaf(Wm[(long)i * C + j], G[i * PBS + t], a);
+            float gxv = a * expf(logs[j]);
+            if (valid) gx[n * gx_ns + (long)j * HW + p] = gxv;
+            float s1 = wave_sum(gxv);
+            float s2 = wave_sum(a * Y[j * PBS + t]);
+            if ((t & 63) == 0) {
+                atomicAdd(&gbias[j], s1);
+                atomicAdd(&glogs[j], s2);
+            }
+        }
+    }
+}
+
+extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const float* bias, const float* logs,
+                                           const float* Wm, const float* gz, long gz_ns, float* gx, long gx_ns,
+                                           float* gW, float* gbias, float* glogs, int N, int C, int HW,
+                                           rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && bias && logs && Wm && gz && gx && gW && gbias && glogs && N >= 0 && C > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    int PB = 256;
+    while ((long)2 * C * (PB + 1) * 4 > 65536 && PB > 64) PB >>= 1;
+    size_t lds = (size_t)2 * C * (PB + 1) * 4;
+    if (lds > 160 * 1024) {
+        rfn_set_error("actnorm_invconv_bwd: C=%d too large", C);
+        return -3;
+    }
+    if (lds > 65536)
+        (void)hipFuncSetAttribute((const void*)actnorm_invconv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            (int)lds);
+    long tot = (long)N * HW;
+    int grid = (int)((tot + PB - 1) / PB);
+    hipLaunchKernelGGL(actnorm_invconv_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, x_ns, bias, logs,
+                       Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ affine coupling
+__device__ __forceinline__ float clamp_ls(float s, int clamp_type, float sc, float sh) {
+    switch (clamp_type) {
+        case 0: return sc * tanhf(s) + sh;
+        case 1: return -log1pf(expf(-(s + 2.0f)));  // log sigmoid(s+2)
+        case 2: return 2.5f * 0.636f * atanf(s / 2.5f);
+        default: return s;
+    }
+}
+// d ls / d s
+__device__ __forceinline__ float clamp_ls_grad(float s, int clamp_type, float sc) {
+    switch (clamp_type) {
+        case 0: {
+            float t = tanhf(s);
+            return sc * (1.0f - t * t);
+        }
+        case 1: return 1.0f / (1.0f + expf(s + 2.0f));  // 1 - sigmoid(s+2)
+        case 2: {
+            float r = s / 2.5f;
+            return 0.636f / (1.0f + r * r);
+        }
+        default: return 1.0f;
+    }
+}
+
+// one block per frame; elements e in [0, C/2*HW): channel j = e / HW
+__global__ __launch_bounds__(256) void affine_coupling_kernel(float* __restrict__ z, long z_ns,
+                                                              const float* __restrict__ o, long o_ns,
+                                                              const float* __restrict__ scale,
+                                                              const float* __restrict__ scale_shift,
+                                                              float* __restrict__ logdet, int clamp_type, int reverse,
+                                                              int C, int HW) {
+    __shared__ float sm[4];
+    const int n = blockIdx.x, Ch = C >> 1;
+    float* z2 = z + n * z_ns + (long)Ch * HW;
+    const float* on = o + n * o_ns;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < Ch * HW; e += 256) {
+        int j = e / HW, p = e - j * HW;
+        float shift = on[(long)(2 * j) * HW + p];
+        float s = on[(long)(2 * j + 1) * HW + p];
+        float sc = 0.f, sh = 0.f;
+        if (clamp_type == 0) {
+            sc = scale[j];
+            sh = scale_shift[j];
+        }
+        float ls = clamp_ls(s, clamp_type, sc, sh);
+        float v = z2[e];
+        if (!reverse)
+            v = (v + shift) * expf(ls);
+        else
+            v = v * expf(-ls) - shift;
+        z2[e] = v;
+        acc += ls;
+    }
+    if (logdet) {
+        float tot = block_sum_256(acc, sm);
+        if (threadIdx.x == 0) logdet[n] += reverse ? -tot : tot;
+    }
+}
+extern "C" int rfn_affine_coupling_f32(float* z, long z_ns, const float* o, long o_ns, const float* scale,
+                                       const float* scale_shift, float* logdet, int clamp_type, int reverse, int N,
+                                       int C, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(z && o && N >= 0 && C > 0 && (C % 2 == 0) && HW > 0, -1);
+    RFN_CHECK_ARG(clamp_type != 0 || (scale && scale_shift), -2);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(affine_coupling_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, z, z_ns, o, o_ns, scale,
+                       scale_shift, logdet, clamp_type, reverse, C, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// backward: grid (N); per-channel parameter grads reduced per block through LDS then atomics.
+__global__ __launch_bounds__(256) void affine_coupling_bwd_kernel(
+    const float* __restrict__ zout, long zout_ns, const float* __restrict__ o, long o_ns,
+    const float* __restrict__ gout, long gout_ns, const float* __restrict__ glogdet, const float* __restrict__ scale,
+    const float* __restrict__ scale_shift, float* __restrict__ gz, long gz_ns, float* __restrict__ go, long go_ns,
+    float* __restrict__ gscale, float* __restrict__ gscale_shift, int clamp_type, int C, int HW) {
+    const int n = blockIdx.x, Ch = C >> 1;
+    const float* z2o = zout + n * zout_ns + (long)Ch * HW;
+    const float* g2 = gout + n * gout_ns + (long)Ch * HW;
+    const float* on = o + n * o_ns;
+    float* gz2 = gz + n * gz_ns + (long)Ch * HW;
+    float* gon = go + n * go_ns;
+    const float gld = glogdet ? glogdet[n] : 0.f;
+    // channel-major sweep so per-channel sums can be wave-reduced: each wave takes channels j = wave, wave+4, ...
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    for (int j = wave; j < Ch; j += 4) {
+        float sc = 0.f, sh = 0.f;
+        if (clamp_type == 0) {
+            sc = scale[j];
+            sh = scale_shift[j];
+        }
+        float a_sc = 0.f, a_sh = 0.f;
+        for (int p = lane; p < HW; p += 64) {
+            float s = on[(long)(2 * j + 1) * HW + p];
+            float ls = clamp_ls(s, clamp_type, sc, sh);
+            float e = expf(ls);
+            float g = g2[(long)j * HW + p];
+            float zo = z2o[(long)j * HW + p];
+            float gls = g * zo + gld;
+            float gzv = g * e;
+            gz2[(long)j * HW + p] = gzv;
+            gon[(long)(2 * j) * HW + p] = gzv;  // d/dshift
+            gon[(long)(2 * j + 1) * HW + p] = gls * clamp_ls_grad(s, clamp_type, sc);
+            if (clamp_type == 0) {
+                a_sc += gls * tanhf(s);
+                a_sh += gls;
+            }
+        }
+        if (clamp_type == 0) {
+            a_sc = wave_sum(a_sc);
+            a_sh = wave_sum(a_sh);
+            if (lane == 0) {
+                atomicAdd(&gscale[j], a_sc);
+                atomicAdd(&gscale_shift[j], a_sh);
+            }
+        }
+    }
+}
+extern "C" int rfn_affine_coupling_bwd_f32(const float* zout, long zout_ns, const float* o, long o_ns,
+                                           const float* gout, long gout_ns, const float* glogdet, const float* scale,
+                                           const float* scale_shift, float* gz, long gz_ns, float* go, long go_ns,
+                                           float* gscale, float* gscale_shift, int clamp_type, int N, int C, int HW,
+                                           rfn_stream_t stream) {
+    RFN_CHECK_ARG(zout && o && gout && gz && go && N >= 0 && C > 0 && (C % 2 == 0) && HW > 0, -1);
+    RFN_CHECK_ARG(clamp_type != 0 || (scale && scale_shift && gscale && gscale_shift), -2);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(affine_coupling_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, zout, zout_ns, o, o_ns,
+                       gout, gout_ns, glogdet, scale, scale_shift, gz, gz_ns, go, go_ns, gscale, gscale_shift, clamp_type,
+                       C, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ gaussian log-prob
+#define RFN_HALF_LOG_2PI 0.91893853320467274178f
+__device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch threshold=20
+
+__device__ __forceinline__ void gauss_params(const float* on, int layout, int c, int Cz, int HW, int p, float& mean,
+                                             float& raw) {
+    if (layout == 0) {
+        mean = on[(long)(2 * c) * HW + p];
+        raw = on[(long)(2 * c + 1) * HW + p];
+    } else {
+        mean = on[(long)c * HW + p];
+        raw = on[(long)(Cz + c) * HW + p];
+    }
+}
+
+__global__ __launch_bounds__(256) void gauss_logp_kernel(const float* __restrict__ z, long z_ns,
+                                                         const float* __restrict__ o, long o_ns,
+                                                         float* __restrict__ logp, int layout, int std_mode, int Cz,
+                                                         int HW) {
+    __shared__ float sm[4];
+    const int n = blockIdx.x;
+    const float* zn = z + n * z_ns;
+    const float* on = o + n * o_ns;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < Cz * HW; e += 256) {
+        int c = e / HW, p = e - c * HW;
+        float mean, raw;
+        gauss_params(on, layout, c, Cz, HW, p, mean, raw);
+        float logstd, std;
+        if (std_mode == 0) {
+            std = softplusf_(raw) + 1e-8f;
+            logstd = logf(std);
+        } else {
+            std = expf(raw);
+            logstd = raw;
+        }
+        float d = zn[e] - mean;
+        acc += -(d * d) / (2.f * std * std) - logstd - RFN_HALF_LOG_2PI;
+    }
+    float tot = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) logp[n] += tot;
+}
+extern "C" int rfn_gauss_logp_f32(const float* z, long z_ns, const float* o, long o_ns, float* logp, int layout,
+                                  int std_mode, int N, int Cz, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(z && o && logp && N >= 0 && Cz > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(gauss_logp_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, z, z_ns, o, o_ns, logp, layout,
+                       std_mode, Cz, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void gauss_logp_bwd_kernel(const float* __restrict__ z, long z_ns,
+                                                             const float* __restrict__ o, long o_ns,
+                                                             const float* __restrict__ glogp, float* __restrict__ gz,
+                                                             long gz_ns, float* __restrict__ go, long go_ns, int layout,
+                                                             int std_mode, int Cz, int HW) {
+    const int n = blockIdx.x;
+    const float* zn = z + n * z_ns;
+    const float* on = o + n * o_ns;
+    float* gzn = gz + n * gz_ns;
+    float* gon = go + n * go_ns;
+    const float g = glogp[n];
+    for (int e = threadIdx.x; e < Cz * HW; e += 256) {
+        int c = e / HW, p = e - c * HW;
+        float mean, raw;
+        gauss_params(on, layout, c, Cz, HW, p, mean, raw);
+        float std, dstd_draw;
+        if (std_mode == 0) {
+            std = softplusf_(raw) + 1e-8f;
+            dstd_draw = raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw));
+        } else {
+            std = expf(raw);
+            dstd_draw = std;
+        }
+        float d = zn[e] - mean;
+        float inv = 1.f / (std * std);
+        float gzv = -d * inv * g;                        // d logp / d z
+        float gstd = (d * d * inv / std - 1.f / std) * g;  // d logp / d std
+        gzn[e] = gzv;
+        if (layout == 0) {
+            gon[(long)(2 * c) * HW + p] = -gzv;
+            gon[(long)(2 * c + 1) * HW + p] = gstd * dstd_draw;
+        } else {
+            gon[(long)c * HW + p] = -gzv;
+            gon[(long)(Cz + c) * HW + p] = gstd * dstd_draw;
+        }
+    }
+}
+extern "C" int rfn_gauss_logp_bwd_f32(const float* z, long z_ns, const float* o, long o_ns, const float* glogp,
+                                      float* gz, long gz_ns, float* go, long go_ns, int layout, int std_mode, int N,
+                                      int Cz, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(z && o && glogp && gz && go && N >= 0 && Cz > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(gauss_logp_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, z, z_ns, o, o_ns, glogp, gz,
+                       gz_ns, go, go_ns, layout, std_mode, Cz, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ __launch_bounds__(256) void gauss_sample_kernel(const float* __restrict__ o, long o_ns,
+                                                           const float* __restrict__ eps, float* __restrict__ z,
+                                                           long z_ns, float temperature, int layout, int std_mode,
+                                                           int Cz, int HW) {
+    const int n = blockIdx.x;
+    const float* on = o + n * o_ns;
+    for (int e = threadIdx.x; e < Cz * HW; e += 256) {
+        int c = e / HW, p = e - c * HW;
+        float mean, raw;
+        gauss_params(on, layout, c, Cz, HW, p, mean, raw);
+        float std = std_mode == 0 ? softplusf_(raw) + 1e-8f : expf(raw);
+        z[n * z_ns + e] = mean + std * temperature * eps[(long)n * Cz * HW + e];
+    }
+}
+extern "C" int rfn_gauss_sample_f32(const float* o, long o_ns, const float* eps, float* z, long z_ns, float temperature,
+                                    int layout, int std_mode, int N, int Cz, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(o && eps && z && N >= 0 && Cz > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(gauss_sample_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, o, o_ns, eps, z, z_ns,
+                       temperature, layout, std_mode, Cz, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ conv epilogue bwd
+// grid (C, S): block (c, s) sweeps frames n = s, s+S, ... of channel c.
+__global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const float* __restrict__ y, long y_ns,
+                                                                const float* __restrict__ gy, long gy_ns,
+                                                                float* __restrict__ gu, long gu_ns,
+                                                                const float* __restrict__ logs, float* __restrict__ gb,
+                                                                float* __restrict__ gl, int N, int C, int HW,
+                                                                int ep_mode, int act) {
+    __shared__ float sm[4];
+    const int c = blockIdx.x;
+    float e = 1.f;
+    if (ep_mode == 1) e = expf(logs[c]);
+    if (ep_mode == 2) e = expf(3.f * logs[c]);
+    float a_b = 0.f, a_l = 0.f;
+    for (int n = blockIdx.y; n < N; n += gridDim.y) {
+        const float* yp = y ? y + n * y_ns + (long)c * HW : nullptr;
+        const float* gp = gy + n * gy_ns + (long)c * HW;
+        float* up = gu + n * gu_ns + (long)c * HW;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            float g = gp[p];
+            float yv = yp ? yp[p] : 0.f;
+            float slope = 1.f;
+            if (ep_mode == 1) {
+                if (act == 1) slope = yv > 0.f ? 1.f : 0.f;
+                if (act == 2) slope = yv > 0.f ? 1.f : 0.2f;
+            }
+            float u = g * slope * e;
+            up[p] = u;
+            a_b += u;
+            a_l += g * yv;
+        }
+    }
+    float tb = block_sum_256(a_b, sm);
+    float tl = block_sum_256(a_l, sm);
+    if (threadIdx.x == 0) {
+        if (gb) atomicAdd(&gb[c], tb);
+        if (gl && ep_mode != 3) atomicAdd(&gl[c], ep_mode == 2 ? 3.f * tl : tl);
+    }
+}
+extern "C" int rfn_conv_epilogue_bwd_f32(const float* y, long y_ns, const float* gy, long gy_ns, float* gu, long gu_ns,
+                                         const float* logs, float* gb, float* gl, int N, int C, int HW, int ep_mode,
+                                         int act, rfn_stream_t stream) {
+    RFN_CHECK_ARG(gy && gu && N >= 0 && C > 0 && HW > 0, -1);
+    RFN_CHECK_ARG(ep_mode == 3 || (y && logs), -2);
+    if (N == 0) return 0;
+    int S = 2048 / C;
+    if (S < 1) S = 1;
+    if (S > N) S = N;
+    hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3(C, S), dim3(256), 0, (hipStream_t)stream, y, y_ns, gy, gy_ns, gu,
+                       gu_ns, logs, gb, gl, N, C, HW, ep_mode, act);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ ConvLSTM gates
+__global__ void convlstm_gates_fwd_kernel(const float* __restrict__ cc, const float* __restrict__ c_prev, long c_ns,
+                                          const float* __restrict__ Wci, const float* __restrict__ Wcf,
+                                          const float* __restrict__ Wco, float* __restrict__ h_out, long h_ns,
+                                          float* __restrict__ c_out, long co_ns, float* __restrict__ gates, int N,
+                                          int Hc, int HW) {
+    const long per = (long)Hc * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)N * per;
+         idx += (long)gridDim.x * blockDim.x) {
+        int n = (int)(idx / per);
+        long e = idx - n * per;  // channel*HW + p
+        const float* ccn = cc + (long)n * 4 * per;
+        float cp = c_prev[n * c_ns + e];
+        float wi = Wci ? Wci[e] : 0.f, wf = Wcf ? Wcf[e] : 0.f, wo = Wco ? Wco[e] : 0.f;
+        float i = 1.f / (1.f + expf(-(ccn[e] + wi * cp)));
+        float f = 1.f / (1.f + expf(-(ccn[per + e] + wf * cp)));
+        float g = tanhf(ccn[3 * per + e]);
+        float cn = f * cp + i * g;
+        float o = 1.f / (1.f + expf(-(ccn[2 * per + e] + wo * cn)));
+        h_out[n * h_ns + e] = o * tanhf(cn);
+        c_out[n * co_ns + e] = cn;
+        if (gates) {
+            float* gn = gates + (long)n * 4 * per;
+            gn[e] = i;
+            gn[per + e] = f;
+            gn[2 * per + e] = o;
+            gn[3 * per + e] = g;
+        }
+    }
+}
+extern "C" int rfn_convlstm_gates_fwd_f32(const float* cc, const float* c_prev, long c_ns, const float* Wci,
+                                          const float* Wcf, const float* Wco, float* h_out, long h_ns, float* c_out,
+                                          long co_ns, float* gates, int N, int Hc, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(cc && c_prev && h_out && c_out && N >= 0 && Hc > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    long tot = (long)N * Hc * HW;
+    int grid = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
+    hipLaunchKernelGGL(convlstm_gates_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, cc, c_prev, c_ns, Wci,
+                       Wcf, Wco, h_out, h_ns, c_out, co_ns, gates, N, Hc, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+__global__ void convlstm_gates_bwd_kernel(const float* __restrict__ gates, const float* __restrict__ c_prev, long c_ns,
+                                          const float* __restrict__ c_out, long co_ns, const float* __restrict__ gh,
+                                          long gh_ns, const float* __restrict__ gc_next, long gcn_ns,
+                                          const float* __restrict__ Wci, const float* __restrict__ Wcf,
+                                          const float* __restrict__ Wco, float* __restrict__ gcc,
+                                          float* __restrict__ gc_prev, long gcp_ns, int N, int Hc, int HW) {
+    const long per = (long)Hc * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < (long)N * per;
+         idx += (long)gridDim.x * blockDim.x) {
+        int n = (int)(idx / per);
+        long e = idx - n * per;
+        const float* gn = gates + (long)n * 4 * per;
+        float i = gn[e], f = gn[per + e], o = gn[2 * per + e], g = gn[3 * per + e];
+        float cp = c_prev[n * c_ns + e];
+        float cn = c_out[n * co_ns + e];
+        float wi = Wci ? Wci[e] : 0.f, wf = Wcf ? Wcf[e] : 0.f, wo = Wco ? Wco[e] : 0.f;
+        float ghv = gh ? gh[n * gh_ns + e] : 0.f;
+        float gcn = gc_next ? gc_next[n * gcn_ns + e] : 0.f;
+        float tc = tanhf(cn);
+        float go_pre = ghv * tc * o * (1.f - o);  // grad wrt (cc_o + Wco*cn)
+        float gc = gcn + ghv * o * (1.f - tc * tc) + go_pre * wo;
+        float gi_pre = gc * g * i * (1.f - i);
+        float gf_pre = gc * cp * f * (1.f - f);
+        float gg_pre = gc * i * (1.f - g * g);
+        float* gccn = gcc + (long)n * 4 * per;
+        gccn[e] = gi_pre;
+        gccn[per + e] = gf_pre;
+        gccn[2 * per + e] = go_pre;
+        gccn[3 * per + e] = gg_pre;
+        gc_prev[n * gcp_ns + e] = gc * f + gi_pre * wi + gf_pre * wf;
+    }
+}
+extern "C" int rfn_convlstm_gates_bwd_f32(const float* gates, const float* c_prev, long c_ns, const float* c_out,
+                                          long co_ns, const float* gh, long gh_ns, const float* gc_next, long gcn_ns,
+                                          const float* Wci, const float* Wcf, const float* Wco, float* gcc,
+                                          float* gc_prev, long gcp_ns, int N, int Hc, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(gates && c_prev && c_out && gcc && gc_prev && N >= 0 && Hc > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    long tot = (long)N * Hc * HW;
+    int grid = (int)((tot + 255) / 256 < 2048 ? (tot + 255) / 256 : 2048);
+    hipLaunchKernelGGL(convlstm_gates_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, gates, c_prev, c_ns,
+                       c_out, co_ns, gh, gh_ns, gc_next, gcn_ns, Wci, Wcf, Wco, gcc, gc_prev, gcp_ns, N, Hc, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}

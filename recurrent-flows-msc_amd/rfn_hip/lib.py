@@ -1,0 +1,104 @@
+"""ctypes binding of librfn_hip.so (the C ABI declared in include/rfn_hip.h).
+
+The library is built in-tree by `make -C recurrent-flows-msc_amd/csrc` (see __graft_entry__.build) and is the
+ONLY compute backend of this package: if it cannot be loaded, or a tensor is not a contiguous fp32 device tensor,
+the call raises — there is no CPU / eager fallback.
+"""
+import ctypes
+import os
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "librfn_hip.so")
+
+_c_f = ctypes.c_void_p  # device float*
+_c_i = ctypes.c_int
+_c_l = ctypes.c_long
+_c_s = ctypes.c_void_p  # hipStream_t
+
+# name -> argtypes (restype is int unless listed in _RESTYPES); order mirrors include/rfn_hip.h
+SIGNATURES = {
+    "rfn_abi_version": [],
+    "rfn_last_error": [],
+    "rfn_squeeze2d_f32": [_c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_channel_stats_f32": [_c_f, _c_l, _c_f, _c_f, _c_i, _c_i, _c_i, _c_s],
+    "rfn_actnorm_invconv_fwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_i, _c_i, _c_i, _c_s],
+    "rfn_actnorm_invconv_bwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f,
+                                    _c_i, _c_i, _c_i, _c_s],
+    "rfn_invconv_actnorm_rev_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_i, _c_i, _c_i, _c_s],
+    "rfn_conv2d_fwd_f32": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
+                           _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
+    "rfn_packed_weight_size": [_c_i, _c_i, _c_i],
+    "rfn_pack_conv_weight_f32": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_conv2d_wgrad_f32": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_wgrad_finish_f32": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_conv_epilogue_bwd_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                  _c_s],
+    "rfn_affine_coupling_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_affine_coupling_bwd_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l,
+                                    _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_gauss_logp_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_gauss_logp_bwd_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i,
+                               _c_s],
+    "rfn_gauss_sample_f32": [_c_f, _c_l, _c_f, _c_f, _c_l, ctypes.c_float, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_convlstm_gates_fwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,
+                                   _c_s],
+    "rfn_convlstm_gates_bwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f,
+                                   _c_l, _c_i, _c_i, _c_i, _c_s],
+}
+_RESTYPES = {"rfn_last_error": ctypes.c_char_p, "rfn_packed_weight_size": ctypes.c_long}
+
+_lib = None
+
+
+def load():
+    """Load librfn_hip.so (once).  Raises RuntimeError if the extension has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RuntimeError(
+            "librfn_hip.so not found at %s — build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C recurrent-flows-msc_amd/csrc`. There is no fallback path." % LIB_PATH)
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPES.get(name, ctypes.c_int)
+    _lib = lib
+    return lib
+
+
+def call(name, *args):
+    """Invoke an int-returning entry point on the current torch stream; raise on a non-zero code."""
+    lib = load()
+    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
+    rc = getattr(lib, name)(*args, stream)
+    if rc != 0:
+        raise RuntimeError("%s failed (code %d): %s" % (name, rc, lib.rfn_last_error().decode()))
+
+
+def dev(t, name="tensor"):
+    """Validate a device tensor for the kernels and return its pointer: fp32, on the GPU, inner dims contiguous."""
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise RuntimeError("rfn_hip kernels need device tensors; %s is on %s (no CPU fallback)" % (name, t.device))
+    if t.dtype != torch.float32:
+        raise RuntimeError("rfn_hip kernels are fp32; %s is %s" % (name, t.dtype))
+    return ctypes.c_void_p(t.data_ptr())
+
+
+def frames(t, name="tensor"):
+    """(pointer, frame stride) of an [N,C,H,W] (or [N,C,HW]) tensor whose per-frame block is dense."""
+    p = dev(t, name)
+    shape, stride = t.shape, t.stride()
+    exp = 1
+    for d in range(t.dim() - 1, 0, -1):
+        if shape[d] != 1 and stride[d] != exp:
+            raise RuntimeError("%s: per-frame layout must be dense NCHW, got shape %s stride %s" %
+                               (name, tuple(shape), tuple(stride)))
+        exp *= shape[d]
+    ns = stride[0] if shape[0] > 1 else exp
+    return p, int(ns)

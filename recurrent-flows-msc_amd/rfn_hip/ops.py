@@ -1,0 +1,405 @@
+"""Tensor-level wrappers and autograd Functions over the C ABI (include/rfn_hip.h).
+
+Everything here runs on the GPU through librfn_hip.so; torch is used for memory, streams and autograd plumbing.
+Frame-batched layout: tensors are [N, C, H, W] fp32 where N = all frames handed over by the caller (the RFN driver
+time-batches B*(T-1) frames into one call).
+"""
+import ctypes
+
+import torch
+
+from . import lib as L
+
+_i = ctypes.c_int
+_l = ctypes.c_long
+
+ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
+CLAMP = {"realnvp": 0, "glow": 1, "softclamp": 2, "none": 3}
+
+
+def _hw(t):
+    return int(t.shape[2]) * int(t.shape[3])
+
+
+# ----------------------------------------------------------------------------------------------- raw kernels
+def squeeze2d_raw(x, undo=False):
+    N, C, H, W = x.shape
+    xp, xns = L.frames(x, "x")
+    if not undo:
+        y = torch.empty((N, C * 4, H // 2, W // 2), device=x.device, dtype=x.dtype)
+    else:
+        y = torch.empty((N, C // 4, H * 2, W * 2), device=x.device, dtype=x.dtype)
+    yp, yns = L.frames(y, "y")
+    L.call("rfn_squeeze2d_f32", xp, _l(xns), yp, _l(yns), _i(N), _i(C), _i(H), _i(W), _i(1 if undo else 0))
+    return y
+
+
+def channel_stats(x):
+    """per-channel (mean, unbiased variance) over (N,H,W) — ActNorm data dependent init."""
+    N, C = x.shape[0], x.shape[1]
+    xp, xns = L.frames(x, "x")
+    mean = torch.empty(C, device=x.device, dtype=torch.float32)
+    var = torch.empty(C, device=x.device, dtype=torch.float32)
+    L.call("rfn_channel_stats_f32", xp, _l(xns), L.dev(mean), L.dev(var), _i(N), _i(C), _i(_hw(x)))
+    return mean, var
+
+
+def actnorm_invconv_fwd(x, bias, logs, Wm):
+    N, C = x.shape[0], x.shape[1]
+    xp, xns = L.frames(x, "x")
+    z = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    zp, zns = L.frames(z, "z")
+    L.call("rfn_actnorm_invconv_fwd_f32", xp, _l(xns), L.dev(bias.contiguous()), L.dev(logs.contiguous()),
+           L.dev(Wm.contiguous()), zp, _l(zns), _i(N), _i(C), _i(_hw(x)))
+    return z
+
+
+def actnorm_invconv_bwd(x, bias, logs, Wm, gz):
+    N, C = x.shape[0], x.shape[1]
+    xp, xns = L.frames(x, "x")
+    gzp, gzns = L.frames(gz, "gz")
+    gx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
+    gxp, gxns = L.frames(gx, "gx")
+    gW = torch.zeros((C, C), device=x.device, dtype=torch.float32)
+    gb = torch.zeros(C, device=x.device, dtype=torch.float32)
+    gl = torch.zeros(C, device=x.device, dtype=torch.float32)
+    L.call("rfn_actnorm_invconv_bwd_f32", xp, _l(xns), L.dev(bias.contiguous()), L.dev(logs.contiguous()),
+           L.dev(Wm.contiguous()), gzp, _l(gzns), gxp, _l(gxns), L.dev(gW), L.dev(gb), L.dev(gl), _i(N), _i(C),
+           _i(_hw(x)))
+    return gx, gW, gb, gl
+
+
+def invconv_actnorm_rev(z, bias, logs, Winv):
+    N, C = z.shape[0], z.shape[1]
+    zp, zns = L.frames(z, "z")
+    x = torch.empty(z.shape, device=z.device, dtype=z.dtype)
+    xp, xns = L.frames(x, "x")
+    L.call("rfn_invconv_actnorm_rev_f32", zp, _l(zns), L.dev(bias.contiguous()), L.dev(logs.contiguous()),
+           L.dev(Winv.contiguous()), xp, _l(xns), _i(N), _i(C), _i(_hw(z)))
+    return x
+
+
+def pack_weight(w, flip=False):
+    """Pack a torch-layout conv weight [Cout,Cin,k,k] for the MFMA conv kernel (flip=True: data-gradient conv).
+    One streaming kernel over the packed buffer; done per call (weights change every optimizer step)."""
+    Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+    size = L.load().rfn_packed_weight_size(Cout, Cin, ks)
+    wpk = torch.empty(size, device=w.device, dtype=torch.float32)
+    wc = w.detach().contiguous()
+    L.call("rfn_pack_conv_weight_f32", L.dev(wc, "w"), L.dev(wpk), _i(Cout), _i(Cin), _i(ks), _i(1 if flip else 0))
+    return wpk
+
+
+def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1=None, out2=None, cout_split=None,
+               acc1=False, acc2=False):
+    """out = epilogue(conv(cat(in1,in2))) ; see rfn_conv2d_fwd_f32."""
+    N, C1, H, W = in1.shape
+    C2 = 0 if in2 is None else int(in2.shape[1])
+    i1p, i1ns = L.frames(in1, "in1")
+    i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
+    if cout_split is None:
+        cout_split = Cout
+    if out1 is None:
+        out1 = torch.empty((N, cout_split, H, W), device=in1.device, dtype=torch.float32)
+    o1p, o1ns = L.frames(out1, "out1")
+    o2p, o2ns = (None, 0) if out2 is None else L.frames(out2, "out2")
+    L.call("rfn_conv2d_fwd_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(wpk), o1p, _l(o1ns), o2p,
+           _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W), _i(ks),
+           _i(ep_mode), L.dev(p0), L.dev(p1), _i(act))
+    return out1
+
+
+def conv2d_wgrad(in1, in2, g, Cout, ks):
+    """returns gw [Cout, Cin, ks, ks]"""
+    N, C1, H, W = in1.shape
+    C2 = 0 if in2 is None else int(in2.shape[1])
+    Cin = C1 + C2
+    i1p, i1ns = L.frames(in1, "in1")
+    i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
+    gp, gns = L.frames(g, "g")
+    gwt = torch.zeros((ks * ks, Cout, Cin), device=in1.device, dtype=torch.float32)
+    L.call("rfn_conv2d_wgrad_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), gp, _l(gns), _i(Cout), L.dev(gwt),
+           _i(N), _i(H), _i(W), _i(ks))
+    gw = torch.empty((Cout, Cin, ks, ks), device=in1.device, dtype=torch.float32)
+    L.call("rfn_wgrad_finish_f32", L.dev(gwt), L.dev(gw), _i(Cout), _i(Cin), _i(ks), _i(0))
+    return gw
+
+
+def conv_epilogue_bwd(y, gy, logs, ep_mode, act, want_gl=True):
+    """in-place on gy: gy <- gu ; returns (gu, gb, gl)"""
+    N, C = gy.shape[0], gy.shape[1]
+    yp, yns = (None, 0) if y is None else L.frames(y, "y")
+    gp, gns = L.frames(gy, "gy")
+    gb = torch.zeros(C, device=gy.device, dtype=torch.float32)
+    gl = torch.zeros(C, device=gy.device, dtype=torch.float32) if want_gl else None
+    L.call("rfn_conv_epilogue_bwd_f32", yp, _l(yns), gp, _l(gns), gp, _l(gns), L.dev(logs), L.dev(gb), L.dev(gl),
+           _i(N), _i(C), _i(_hw(gy)), _i(ep_mode), _i(act))
+    return gy, gb, gl
+
+
+def affine_coupling_(z, o, scale, scale_shift, logdet, clamp_type, reverse):
+    """in place on z's second channel half; logdet [N] updated in place (may be None)."""
+    N, C = z.shape[0], z.shape[1]
+    zp, zns = L.frames(z, "z")
+    op, ons = L.frames(o, "o")
+    L.call("rfn_affine_coupling_f32", zp, _l(zns), op, _l(ons), L.dev(scale), L.dev(scale_shift), L.dev(logdet),
+           _i(clamp_type), _i(1 if reverse else 0), _i(N), _i(C), _i(_hw(z)))
+
+
+def gauss_logp(z, o, layout, std_mode):
+    N, Cz = z.shape[0], z.shape[1]
+    zp, zns = L.frames(z, "z")
+    op, ons = L.frames(o, "o")
+    logp = torch.zeros(N, device=z.device, dtype=torch.float32)
+    L.call("rfn_gauss_logp_f32", zp, _l(zns), op, _l(ons), L.dev(logp), _i(layout), _i(std_mode), _i(N), _i(Cz),
+           _i(_hw(z)))
+    return logp
+
+
+def gauss_sample(o, eps, layout, std_mode, temperature):
+    N, C2 = o.shape[0], o.shape[1]
+    Cz = C2 // 2
+    z = torch.empty((N, Cz) + tuple(o.shape[2:]), device=o.device, dtype=torch.float32)
+    op, ons = L.frames(o, "o")
+    zp, zns = L.frames(z, "z")
+    L.call("rfn_gauss_sample_f32", op, _l(ons), L.dev(eps.contiguous(), "eps"), zp, _l(zns),
+           ctypes.c_float(float(temperature)), _i(layout), _i(std_mode), _i(N), _i(Cz), _i(_hw(o)))
+    return z
+
+
+# ----------------------------------------------------------------------------------------------- autograd Functions
+class Squeeze2dFn(torch.autograd.Function):
+    """Flow/glow_modules.py:298-310; backward = the opposite permutation."""
+
+    @staticmethod
+    def forward(ctx, x, undo):
+        ctx.undo = undo
+        return squeeze2d_raw(x, undo)
+
+    @staticmethod
+    def backward(ctx, g):
+        return squeeze2d_raw(g.contiguous(), not ctx.undo), None
+
+
+class ConvFn(torch.autograd.Function):
+    """epilogue(conv(cat(in1, in2), w)) with the epilogue of rfn_conv2d_fwd_f32.
+    p0/p1: ep_mode 1 -> (actnorm bias, actnorm logs); 2 -> (conv bias, logs); 3 -> (conv bias, None)."""
+
+    @staticmethod
+    def forward(ctx, in1, in2, w, p0, p1, ep_mode, act):
+        Cout, ks = int(w.shape[0]), int(w.shape[2])
+        p0f = None if p0 is None else p0.detach().reshape(-1).contiguous()
+        p1f = None if p1 is None else p1.detach().reshape(-1).contiguous()
+        y = conv2d_raw(in1, in2, pack_weight(w), Cout, ks, ep_mode, p0f, p1f, act)
+        ctx.save_for_backward(in1, in2, w, p1f, y)
+        ctx.cfg = (ep_mode, act, None if p0 is None else p0.shape, None if p1 is None else p1.shape)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        in1, in2, w, p1f, y = ctx.saved_tensors
+        ep_mode, act, p0shape, p1shape = ctx.cfg
+        Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+        gy = gy.contiguous().clone() if ep_mode != 0 else gy.contiguous()
+        gp0 = gp1 = None
+        if ep_mode != 0:
+            gy, gb, gl = conv_epilogue_bwd(y if ep_mode != 3 else None, gy, p1f, ep_mode, act, ep_mode != 3)
+            gp0 = gb.view(p0shape)
+            gp1 = gl.view(p1shape) if gl is not None else None
+        g1 = g2 = gw = None
+        C1 = int(in1.shape[1])
+        need1, need2 = ctx.needs_input_grad[0], in2 is not None and ctx.needs_input_grad[1]
+        if need1 or need2:
+            wt = pack_weight(w, flip=True)
+            N, _, H, W = in1.shape
+            g1 = torch.empty(in1.shape, device=gy.device, dtype=torch.float32)
+            if in2 is not None:
+                g2 = torch.empty(in2.shape, device=gy.device, dtype=torch.float32)
+            conv2d_raw(gy, None, wt, Cin, ks, 0, None, None, 0, out1=g1, out2=g2, cout_split=C1)
+        if ctx.needs_input_grad[2]:
+            gw = conv2d_wgrad(in1, in2, gy, Cout, ks)
+        return g1, g2, gw, gp0, gp1, None, None
+
+
+def conv_ep(in1, in2, w, p0, p1, ep_mode, act):
+    return ConvFn.apply(in1, in2, w, p0, p1, ep_mode, act)
+
+
+class GlowStepFn(torch.autograd.Function):
+    """One forward Glow step (Flow/glow.py:31-36) as a single autograd node:
+         y  = (x + an_bias) * exp(an_logs)                       glow_modules.py:38-45
+         z  = Wm y                                               glow_modules.py:209-216
+         h1 = act(actnorm(conv3x3(cat(z1, cond))))               glow_modules.py:232-238, 139-142
+         h2 = act(actnorm(conv1x1(h1)))
+         o  = (conv3x3(h2) + b3) * exp(3 logs3)                  glow_modules.py:119-121
+         z2 <- (z2 + o[0::2]) * exp(clamp(o[1::2]))              glow_modules.py:276-285
+       Returns (out, dlogdet[N]) where dlogdet holds only the data dependent Σ clamp(s) part; the parameter-only
+       terms (Σlogs + Σlog_s)·H·W are added by the caller.
+       Saved for backward: x, cond, out, h1, h2, o (activations stay resident in HBM, 288 GB is plenty)."""
+
+    @staticmethod
+    def forward(ctx, x, cond, Wm, an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift,
+                act, clamp_type):
+        N, C, H, W = x.shape
+        Ch = C // 2
+        Hd = int(w1.shape[0])
+        f = lambda t: None if t is None else t.detach().reshape(-1).contiguous()
+        out = actnorm_invconv_fwd(x, f(an_bias), f(an_logs), Wm.detach())
+        z1 = out[:, :Ch]
+        cin2 = cond if cond.shape[1] > 0 else None
+        h1 = conv2d_raw(z1, cin2, pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b), f(n1l), act)
+        h2 = conv2d_raw(h1, None, pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b), f(n2l), act)
+        o = conv2d_raw(h2, None, pack_weight(w3), C, int(w3.shape[2]), 2, f(b3), f(l3), 0)
+        dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
+        affine_coupling_(out, o, f(scale), f(scale_shift), dlogdet, clamp_type, False)
+        ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o)
+        ctx.cfg = (act, clamp_type)
+        return out, dlogdet
+
+    @staticmethod
+    def backward(ctx, gout, gdl):
+        (x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o) = ctx.saved_tensors
+        act, clamp_type = ctx.cfg
+        N, C, H, W = x.shape
+        Ch, HW = C // 2, H * W
+        Hd = int(w1.shape[0])
+        dev = x.device
+        f = lambda t: None if t is None else t.detach().reshape(-1).contiguous()
+        gout = gout.contiguous()
+        gdl = None if gdl is None else gdl.contiguous()
+        # ---- affine bwd: gz (z1 half = gout z1 half, z2 half computed), go
+        gz = gout.clone()
+        go = torch.empty_like(o)
+        gscale = gshift = None
+        if clamp_type == 0:
+            gscale = torch.zeros(Ch, device=dev, dtype=torch.float32)
+            gshift = torch.zeros(Ch, device=dev, dtype=torch.float32)
+        op, ons = L.frames(o, "o")
+        outp, outns = L.frames(out, "out")
+        gop, gons = L.frames(gout, "gout")
+        gzp, gzns = L.frames(gz, "gz")
+        gonp, gonns = L.frames(go, "go")
+        L.call("rfn_affine_coupling_bwd_f32", outp, _l(outns), op, _l(ons), gop, _l(gons), L.dev(gdl), L.dev(f(scale)),
+               L.dev(f(scale_shift)), gzp, _l(gzns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), _i(clamp_type),
+               _i(N), _i(C), _i(HW))
+        # ---- conv3 (Conv2dZeros) bwd
+        go, gb3, gl3 = conv_epilogue_bwd(o, go, f(l3), 2, 0)
+        gw3 = conv2d_wgrad(h2, None, go, C, int(w3.shape[2]))
+        gh2 = conv2d_raw(go, None, pack_weight(w3, True), Hd, int(w3.shape[2]))
+        # ---- actnorm2 + act bwd, conv2 (1x1) bwd
+        gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, f(n2l), 1, act)
+        gw2 = conv2d_wgrad(h1, None, gh2, Hd, int(w2.shape[2]))
+        gh1 = conv2d_raw(gh2, None, pack_weight(w2, True), Hd, int(w2.shape[2]))
+        # ---- actnorm1 + act bwd, conv1 bwd (grad flows to z1 (accumulated into gz's first half) and to cond)
+        gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, f(n1l), 1, act)
+        z1 = out[:, :Ch]
+        has_cond = cond.shape[1] > 0
+        gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, int(w1.shape[2]))
+        gcond = torch.empty_like(cond) if has_cond else torch.zeros_like(cond)
+        conv2d_raw(gh1, None, pack_weight(w1, True), Ch + int(cond.shape[1]), int(w1.shape[2]), 0, None, None, 0,
+                   out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True, acc2=False)
+        # ---- invconv + actnorm bwd
+        gx, gW, gab, gal = actnorm_invconv_bwd(x, f(an_bias), f(an_logs), Wm.detach(), gz)
+        return (gx, gcond, gW, gab.view(an_bias.shape), gal.view(an_logs.shape), gw1, gn1b.view(1, -1, 1, 1),
+                gn1l.view(n1l.shape), gw2, gn2b.view(1, -1, 1, 1), gn2l.view(n2l.shape), gw3, gb3, gl3.view(l3.shape),
+                None if gscale is None else gscale.view(scale.shape),
+                None if gshift is None else gshift.view(scale_shift.shape), None, None)
+
+
+class GlowStepRevFn(torch.autograd.Function):
+    """Reverse Glow step (Flow/glow.py:37-41) for generation; no gradient (the reference samples under no_grad)."""
+
+    @staticmethod
+    def forward(ctx, x, cond, Winv, an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift,
+                act, clamp_type):
+        N, C, H, W = x.shape
+        Ch = C // 2
+        Hd = int(w1.shape[0])
+        f = lambda t: None if t is None else t.detach().reshape(-1).contiguous()
+        z = x.detach().clone()
+        cin2 = cond if cond.shape[1] > 0 else None
+        h1 = conv2d_raw(z[:, :Ch], cin2, pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b), f(n1l), act)
+        h2 = conv2d_raw(h1, None, pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b), f(n2l), act)
+        o = conv2d_raw(h2, None, pack_weight(w3), C, int(w3.shape[2]), 2, f(b3), f(l3), 0)
+        dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
+        affine_coupling_(z, o, f(scale), f(scale_shift), dlogdet, clamp_type, True)
+        out = invconv_actnorm_rev(z, f(an_bias), f(an_logs), Winv.detach())
+        ctx.mark_non_differentiable(out, dlogdet)
+        return out, dlogdet
+
+
+class GaussLogpFn(torch.autograd.Function):
+    """Σ log N(z; mean, std) per frame (glow_modules.py:358-365 layout 0/softplus; glow.py:135-140 layout 1/exp)."""
+
+    @staticmethod
+    def forward(ctx, z, o, layout, std_mode):
+        ctx.save_for_backward(z, o)
+        ctx.cfg = (layout, std_mode)
+        return gauss_logp(z, o, layout, std_mode)
+
+    @staticmethod
+    def backward(ctx, g):
+        z, o = ctx.saved_tensors
+        layout, std_mode = ctx.cfg
+        N, Cz = z.shape[0], z.shape[1]
+        gz = torch.empty(z.shape, device=z.device, dtype=torch.float32)
+        go = torch.empty(o.shape, device=z.device, dtype=torch.float32)
+        zp, zns = L.frames(z, "z")
+        op, ons = L.frames(o, "o")
+        gzp, gzns = L.frames(gz, "gz")
+        gop, gons = L.frames(go, "go")
+        L.call("rfn_gauss_logp_bwd_f32", zp, _l(zns), op, _l(ons), L.dev(g.contiguous()), gzp, _l(gzns), gop, _l(gons),
+               _i(layout), _i(std_mode), _i(N), _i(Cz), _i(_hw(z)))
+        return gz, go, None, None
+
+
+class ConvLSTMCellFn(torch.autograd.Function):
+    """ConvLSTMLayer.forward (Utils/modules.py:355-377): conv3x3(cat(x,h))+b on the MFMA conv kernel, then the fused
+    gate update.  Peephole tensors may be None (== 0)."""
+
+    @staticmethod
+    def forward(ctx, x, h, c, w, b, wci, wcf, wco):
+        N, Cx, H, W = x.shape
+        Hc = int(w.shape[0]) // 4
+        ks = int(w.shape[2])
+        HW = H * W
+        cc = conv2d_raw(x, h, pack_weight(w), 4 * Hc, ks, 3 if b is not None else 0,
+                        None if b is None else b.detach().contiguous(), None, 0)
+        h_out = torch.empty((N, Hc, H, W), device=x.device, dtype=torch.float32)
+        c_out = torch.empty((N, Hc, H, W), device=x.device, dtype=torch.float32)
+        gates = torch.empty((N, 4 * Hc, H, W), device=x.device, dtype=torch.float32)
+        cp, cns = L.frames(c, "c")
+        hp, hns = L.frames(h_out, "h_out")
+        cop, cons = L.frames(c_out, "c_out")
+        pe = [None if t is None else t.detach().reshape(-1).contiguous() for t in (wci, wcf, wco)]
+        L.call("rfn_convlstm_gates_fwd_f32", L.dev(cc), cp, _l(cns), L.dev(pe[0]), L.dev(pe[1]), L.dev(pe[2]), hp,
+               _l(hns), cop, _l(cons), L.dev(gates), _i(N), _i(Hc), _i(HW))
+        ctx.save_for_backward(x, h, c, w, gates, c_out, *[t for t in pe if t is not None])
+        ctx.has_bias = b is not None
+        ctx.has_pe = pe[0] is not None
+        return h_out, c_out
+
+    @staticmethod
+    def backward(ctx, gh, gc):
+        saved = ctx.saved_tensors
+        x, h, c, w, gates, c_out = saved[:6]
+        pe = list(saved[6:9]) if ctx.has_pe else [None, None, None]
+        N, Cx, H, W = x.shape
+        Hc = int(w.shape[0]) // 4
+        ks = int(w.shape[2])
+        HW = H * W
+        gcc = torch.empty_like(gates)
+        gc_prev = torch.empty_like(c)
+        cp, cns = L.frames(c, "c")
+        cop, cons = L.frames(c_out, "c_out")
+        ghp, ghns = (None, 0) if gh is None else L.frames(gh.contiguous(), "gh")
+        gcp, gcns = (None, 0) if gc is None else L.frames(gc.contiguous(), "gc")
+        gpp, gpns = L.frames(gc_prev, "gc_prev")
+        L.call("rfn_convlstm_gates_bwd_f32", L.dev(gates), cp, _l(cns), cop, _l(cons), ghp, _l(ghns), gcp, _l(gcns),
+               L.dev(pe[0]), L.dev(pe[1]), L.dev(pe[2]), L.dev(gcc), gpp, _l(gpns), _i(N), _i(Hc), _i(HW))
+        gb = conv_epilogue_bwd(None, gcc, None, 3, 0, want_gl=False)[1] if ctx.has_bias else None
+        gw = conv2d_wgrad(x, h, gcc, 4 * Hc, ks)
+        gx = torch.empty_like(x)
+        ghp_ = torch.empty_like(h)
+        conv2d_raw(gcc, None, pack_weight(w, True), Cx + Hc, ks, 0, None, None, 0, out1=gx, out2=ghp_, cout_split=Cx)
+        return gx, ghp_, gc_prev, gw, gb, None, None, None

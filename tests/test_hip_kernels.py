@@ -1,0 +1,196 @@
+"""GPU parity of the individual gfx950 kernels (through the C ABI via ctypes) against the CPU oracle / plain
+PyTorch fp32 references on seeded inputs.  Integer/index work is bit exact; float work within 1e-4 relative
+(north_star), with the tolerance written at each check."""
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+from oracle import rfn_oracle as O  # noqa: E402
+
+
+@pytest.fixture(scope="module")
+def K():
+    from rfn_hip import ops
+    assert torch.cuda.is_available(), "GPU tests need a device"
+    return ops
+
+
+def cu(t):
+    return t.cuda()
+
+
+def relerr(a, b):
+    a, b = a.detach().cpu().double(), b.detach().cpu().double()
+    return float((a - b).abs().max() / (b.abs().max() + 1e-12))
+
+
+@pytest.mark.parametrize("shape", [(2, 3, 4, 6), (3, 1, 64, 64), (5, 16, 2, 2)])
+def test_squeeze2d_bit_exact(K, shape):
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(shape, generator=g)
+    y = K.squeeze2d_raw(cu(x), False)
+    assert torch.equal(y.cpu(), O.squeeze2d(x))
+    xb = K.squeeze2d_raw(y, True)
+    assert torch.equal(xb.cpu(), x)
+    # strided (channel-slice) input, as produced by Split2d
+    big = torch.randn(shape[0], 2 * shape[1], shape[2], shape[3], generator=g)
+    v = cu(big)[:, : shape[1]]
+    assert torch.equal(K.squeeze2d_raw(v, False).cpu(), O.squeeze2d(big[:, : shape[1]]))
+
+
+def test_squeeze2d_golden(K, golden):
+    f = golden("modules.pt")["squeeze"]
+    assert torch.equal(K.squeeze2d_raw(cu(f["x"]), False).cpu(), f["y"])
+    assert torch.equal(K.squeeze2d_raw(cu(f["y"]), True).cpu(), f["x_back"])
+
+
+def test_channel_stats(K):
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(7, 5, 6, 3, generator=g) * 3 + 1.5
+    mean, var = K.channel_stats(cu(x))
+    xt = x.transpose(0, 1).reshape(5, -1)
+    torch.testing.assert_close(mean.cpu(), xt.mean(1), rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(var.cpu(), xt.var(1, unbiased=True), rtol=1e-5, atol=1e-6)
+
+
+@pytest.mark.parametrize("N,C,H,W", [(3, 4, 5, 3), (2, 8, 4, 4), (5, 64, 2, 2), (2, 12, 8, 8), (70, 2, 2, 2)])
+def test_actnorm_invconv_fwd_bwd_rev(K, N, C, H, W):
+    g = torch.Generator().manual_seed(2)
+    x = torch.randn(N, C, H, W, generator=g, requires_grad=True)
+    b = torch.randn(C, generator=g) * 0.3
+    l = torch.randn(C, generator=g) * 0.2
+    Wm = torch.linalg.qr(torch.randn(C, C, generator=g))[0] + 0.05 * torch.randn(C, C, generator=g)
+    b.requires_grad_(True); l.requires_grad_(True); Wm.requires_grad_(True)
+    y = (x + b.view(1, C, 1, 1)) * l.view(1, C, 1, 1).exp()
+    z = torch.einsum("oc,bchw->bohw", Wm, y)
+    gz = torch.randn(z.shape, generator=g)
+    z.backward(gz)
+    zk = K.actnorm_invconv_fwd(cu(x.detach()), cu(b.detach()), cu(l.detach()), cu(Wm.detach()))
+    assert relerr(zk, z) < 1e-5
+    gx, gW, gb, gl = K.actnorm_invconv_bwd(cu(x.detach()), cu(b.detach()), cu(l.detach()), cu(Wm.detach()), cu(gz))
+    assert relerr(gx, x.grad) < 1e-5
+    assert relerr(gW, Wm.grad) < 1e-4
+    assert relerr(gb, b.grad) < 1e-4
+    assert relerr(gl, l.grad) < 1e-4
+    xr = K.invconv_actnorm_rev(zk, cu(b.detach()), cu(l.detach()), cu(torch.inverse(Wm.detach())))
+    assert relerr(xr, x) < 1e-4
+
+
+CONV_CASES = [
+    # N, C1, C2, Cout, H, W, ks
+    (2, 5, 0, 7, 6, 6, 3),       # odd sizes, non power-of-two map
+    (3, 2, 16, 256, 32, 32, 3),  # level-0 conv1 shape (z1 | cond)
+    (2, 256, 0, 256, 16, 16, 1),  # conv2
+    (2, 256, 0, 4, 32, 32, 3),   # level-0 conv3 (tiny Cout)
+    (9, 32, 256, 256, 2, 2, 3),  # level-4 conv1
+    (5, 256, 0, 64, 2, 2, 3),    # level-4 conv3
+    (3, 12, 0, 40, 4, 4, 1),     # 1x1 with Cin not multiple of 8, Cout 33..64 config
+    (1, 3, 0, 130, 8, 8, 3),     # Cout > 128 (two cout blocks), Cin < 8
+    (2, 9, 0, 20, 64, 64, 3),    # W = 64 (two column tiles)
+    (2, 40, 0, 33, 3, 5, 1),     # 3x5 map
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_fwd_dgrad_wgrad(K, case):
+    N, C1, C2, Cout, H, W, ks = case
+    g = torch.Generator().manual_seed(3)
+    Cin = C1 + C2
+    x1 = torch.randn(N, C1, H, W, generator=g)
+    x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, Cin, ks, ks, generator=g) / (Cin * ks * ks) ** 0.5
+    xin = (torch.cat([x1, x2], 1) if C2 else x1).clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    ref = F.conv2d(xin, wr, None, padding=ks // 2)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    out = K.conv2d_raw(cu(x1), cu(x2) if C2 else None, K.pack_weight(cu(w)), Cout, ks)
+    assert relerr(out, ref) < 2e-5, "forward"
+    # data gradient through the same kernel with flipped/transposed packing, split into the two sources
+    g1 = torch.empty(N, C1, H, W, device="cuda")
+    g2 = torch.empty(N, C2, H, W, device="cuda") if C2 else None
+    K.conv2d_raw(cu(gy), None, K.pack_weight(cu(w), True), Cin, ks, out1=g1, out2=g2, cout_split=C1)
+    assert relerr(g1, xin.grad[:, :C1]) < 2e-5, "dgrad in1"
+    if C2:
+        assert relerr(g2, xin.grad[:, C1:]) < 2e-5, "dgrad in2"
+    gw = K.conv2d_wgrad(cu(x1), cu(x2) if C2 else None, cu(gy), Cout, ks)
+    assert relerr(gw, wr.grad) < 1e-4, "wgrad"
+
+
+@pytest.mark.parametrize("ep_mode,act", [(1, 1), (1, 2), (1, 0), (2, 0), (3, 0)])
+def test_conv_epilogues_fwd_bwd(K, ep_mode, act):
+    g = torch.Generator().manual_seed(4)
+    N, Cin, Cout, H, W = 3, 6, 10, 4, 4
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.2).requires_grad_(True)
+    p0 = (torch.randn(Cout, generator=g) * 0.3).requires_grad_(True)
+    p1 = (torch.randn(Cout, generator=g) * 0.2).requires_grad_(True)
+    xr = x.clone().requires_grad_(True)
+    u = F.conv2d(xr, w, None, padding=1)
+    if ep_mode == 1:
+        ref = O.act_fun((u + p0.view(1, -1, 1, 1)) * p1.view(1, -1, 1, 1).exp(), ["none", "relu", "leakyrelu"][act]) \
+            if act else (u + p0.view(1, -1, 1, 1)) * p1.view(1, -1, 1, 1).exp()
+    elif ep_mode == 2:
+        ref = (u + p0.view(1, -1, 1, 1)) * (3 * p1.view(1, -1, 1, 1)).exp()
+    else:
+        ref = u + p0.view(1, -1, 1, 1)
+    gy = torch.randn(ref.shape, generator=g)
+    ref.backward(gy)
+    xk = cu(x).requires_grad_(True)
+    wk = cu(w.detach()).requires_grad_(True)
+    p0k = cu(p0.detach()).requires_grad_(True)
+    p1k = cu(p1.detach()).requires_grad_(True) if ep_mode != 3 else None
+    out = K.conv_ep(xk, None, wk, p0k, p1k, ep_mode, act)
+    assert relerr(out, ref) < 2e-5
+    out.backward(cu(gy))
+    assert relerr(xk.grad, xr.grad) < 5e-5
+    assert relerr(wk.grad, w.grad) < 1e-4
+    assert relerr(p0k.grad, p0.grad) < 1e-4
+    if ep_mode != 3:
+        assert relerr(p1k.grad, p1.grad) < 1e-4
+
+
+@pytest.mark.parametrize("clamp", ["realnvp", "glow", "softclamp", "none"])
+def test_affine_kernel_fwd_rev(K, clamp):
+    g = torch.Generator().manual_seed(5)
+    N, C, H, W = 4, 6, 3, 5
+    z = torch.randn(N, C, H, W, generator=g)
+    o = torch.randn(N, C, H, W, generator=g)
+    sd = {"scale": torch.randn(C // 2, 1, 1, generator=g) * 0.5, "scale_shift": torch.randn(C // 2, 1, 1, generator=g) * 0.1}
+    shift, s = O.split_feature(o, "cross")
+    ls = O.clamp_log_scale(sd, "", s, clamp)
+    ref = torch.cat((z[:, : C // 2], (z[:, C // 2:] + shift) * ls.exp()), 1)
+    ref_ld = ls.sum(dim=[1, 2, 3])
+    zk = cu(z.clone())
+    ld = torch.zeros(N, device="cuda")
+    K.affine_coupling_(zk, cu(o), cu(sd["scale"].reshape(-1)), cu(sd["scale_shift"].reshape(-1)), ld, K.CLAMP[clamp], False)
+    assert relerr(zk, ref) < 1e-5
+    assert relerr(ld, ref_ld) < 1e-5
+    K.affine_coupling_(zk, cu(o), cu(sd["scale"].reshape(-1)), cu(sd["scale_shift"].reshape(-1)), ld, K.CLAMP[clamp], True)
+    assert relerr(zk, z) < 1e-5
+    assert float(ld.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("layout,std_mode", [(0, 0), (0, 1), (1, 1), (1, 0)])
+def test_gauss_logp_fwd_bwd_sample(K, layout, std_mode):
+    g = torch.Generator().manual_seed(6)
+    N, Cz, H, W = 3, 5, 4, 2
+    z = torch.randn(N, Cz, H, W, generator=g, requires_grad=True)
+    o = (torch.randn(N, 2 * Cz, H, W, generator=g)).requires_grad_(True)
+    mean, raw = O.split_feature(o, "cross" if layout == 0 else "split")
+    std = F.softplus(raw) + 1e-8 if std_mode == 0 else raw.exp()
+    ref = O.normal_log_prob(z, mean, std).sum(dim=(1, 2, 3))
+    gl = torch.randn(N, generator=g)
+    ref.backward(gl)
+    zk = cu(z.detach()).requires_grad_(True)
+    ok = cu(o.detach()).requires_grad_(True)
+    lp = K.GaussLogpFn.apply(zk, ok, layout, std_mode)
+    assert relerr(lp, ref) < 1e-5
+    lp.backward(cu(gl))
+    assert relerr(zk.grad, z.grad) < 1e-5
+    assert relerr(ok.grad, o.grad) < 1e-5
+    eps = torch.randn(N, Cz, H, W, generator=g)
+    zs = K.gauss_sample(cu(o.detach()), cu(eps), layout, std_mode, 0.7)
+    assert relerr(zs, (mean + std * 0.7 * eps)) < 1e-5

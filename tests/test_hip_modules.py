@@ -1,0 +1,259 @@
+"""GPU parity of the drop-in modules (Flow.*, Utils.ConvLSTM, RFN.loss) against the golden vectors produced by the
+reference (tests/golden/*.pt) and against the CPU oracle.  Calls go through the C ABI (ctypes -> librfn_hip.so)."""
+from argparse import Namespace
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import rfn_oracle as O  # noqa: E402
+
+
+def cu(t):
+    return t.cuda()
+
+
+def close(a, b, rtol=1e-4, atol=1e-5):
+    torch.testing.assert_close(a.detach().cpu(), b, rtol=rtol, atol=atol)
+
+
+def load_sd(m, sd):
+    m.load_state_dict({k: (v.float() if v.dtype == torch.float16 else v) for k, v in sd.items()}, strict=True)
+    return m.cuda()
+
+
+def grads_close(m, grads, rtol=2e-3, atol_scale=2e-4):
+    named = dict(m.named_parameters())
+    for k, g in grads.items():
+        got = named[k].grad
+        got = torch.zeros_like(g) if got is None else got.detach().cpu()
+        torch.testing.assert_close(got, g, rtol=rtol, atol=atol_scale * float(g.abs().max()) + 1e-6, msg=lambda s: k + ": " + s)
+
+
+def test_actnorm_init(golden):
+    from Flow import ActNorm
+    f = golden("modules.pt")["actnorm_init"]
+    an = ActNorm(5).cuda().train()
+    y, ld = an(cu(f["x"]), torch.zeros(3, device="cuda"), reverse=False)
+    close(an.bias, f["sd"]["bias"], 1e-5, 1e-6)
+    close(an.logs, f["sd"]["logs"], 1e-5, 1e-6)
+    assert int(an.initialized) == 1
+    close(y, f["y"], 1e-5, 1e-5)
+    close(ld, f["logdet"], 1e-5, 1e-5)
+    xb, ldb = an(y.detach(), torch.zeros(3, device="cuda"), reverse=True)
+    close(xb, f["x_back"], 1e-5, 1e-5)
+    close(ldb, f["logdet_back"], 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("C", [4, 8])
+def test_invconv(golden, C):
+    from Flow import InvConv
+    f = golden("modules.pt")["invconv_lu_%d" % C]
+    ic = load_sd(InvConv(C, True), f["sd"])
+    w, dld = ic.get_weight(cu(f["x"]), False)
+    close(w, f["weight"], 1e-5, 1e-6)
+    x = cu(f["x"]).requires_grad_(True)
+    z, ld = ic(x, torch.zeros(2, device="cuda"), False)
+    close(z, f["z"], 1e-5, 1e-5)
+    close(ld, f["logdet"], 1e-5, 1e-5)
+    (z.square().sum() + ld.sum()).backward()
+    close(x.grad, f["grad_x"], 1e-4, 1e-5)
+    grads_close(ic, f["grads"])
+    xb, ldb = ic(cu(f["z"]), torch.zeros(2, device="cuda"), True)
+    close(xb, f["x_back"], 1e-4, 1e-4)
+    close(ldb, f["logdet_back"], 1e-5, 1e-5)
+
+
+def test_conv2dnorm_zeros(golden):
+    from Flow import Conv2dNorm, Conv2dZeros
+    m = golden("modules.pt")
+    f = m["conv2dnorm"]
+    cn = load_sd(Conv2dNorm(5, 7), f["sd"]).train()
+    close(cn(cu(f["x"])), f["y"], 1e-5, 1e-5)
+    cn0 = Conv2dNorm(5, 7).cuda().train()
+    with torch.no_grad():
+        cn0.conv.weight.copy_(f["sd"]["conv.weight"])
+    close(cn0(cu(f["x"])), f["y_first"], 1e-4, 1e-5)
+    close(cn0.norm_type.logs, f["sd"]["norm_type.logs"], 1e-4, 1e-5)
+    f = m["conv2dnorm_1x1"]
+    cn1 = Conv2dNorm(5, 7, kernel_size=[1, 1]).cuda().train()
+    with torch.no_grad():
+        cn1.conv.weight.copy_(f["sd"]["conv.weight"])
+    close(cn1(cu(f["x"])), f["y"], 1e-4, 1e-5)
+    f = m["conv2dzeros"]
+    cz = load_sd(Conv2dZeros(5, 6), f["sd"])
+    close(cz(cu(f["x"])), f["y"], 1e-5, 1e-5)
+
+
+@pytest.mark.parametrize("clamp", ["realnvp", "glow", "softclamp", "none"])
+@pytest.mark.parametrize("non_lin", ["relu", "leakyrelu"])
+def test_affine_coupling(golden, clamp, non_lin):
+    from Flow import AffineCoupling
+    f = golden("modules.pt")["affine_%s_%s" % (clamp, non_lin)]
+    ac = load_sd(AffineCoupling([2, 6, 4, 4], [2, 5, 4, 4], 16, non_lin, clamp), f["sd"]).train()
+    x = cu(f["x"]).requires_grad_(True)
+    c = cu(f["cond"]).requires_grad_(True)
+    y, ld = ac(x, c, torch.zeros(2, device="cuda"), False)
+    close(y, f["y"], 1e-5, 1e-5)
+    close(ld, f["logdet"], 1e-4, 1e-5)
+    ((y * cu(f["wgt"])).sum() + (ld * cu(f["gld"])).sum()).backward()
+    close(x.grad, f["grad_x"], 1e-4, 1e-5)
+    close(c.grad, f["grad_cond"], 1e-4, 1e-5)
+    grads_close(ac, f["grads"])
+    xb, ldb = ac(cu(f["y"]), cu(f["cond"]), torch.zeros(2, device="cuda"), True)
+    close(xb, f["x_back"], 1e-4, 1e-5)
+    close(ldb, f["logdet_back"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("cond_on", [True, False])
+@pytest.mark.parametrize("clampf", ["softplus", "exp"])
+def test_split2d(golden, cond_on, clampf):
+    from Flow import Split2d
+    f = golden("modules.pt")["split2d_%s_%s" % ("cond" if cond_on else "uncond", clampf)]
+    sp = load_sd(Split2d([2, 8, 4, 4], [2, 6, 4, 4], cond_on, clampf), f["sd"]).train()
+    x = cu(f["x"]).requires_grad_(True)
+    c = cu(f["cond"]).requires_grad_(True)
+    z1, ld = sp(x, c, torch.zeros(2, device="cuda"), False)
+    assert torch.equal(z1.detach().cpu(), f["z1"])
+    close(ld, f["logdet"], 1e-4, 1e-5)
+    ((z1 * cu(f["wgt"])).sum() + (ld * cu(f["gld"])).sum()).backward()
+    close(x.grad, f["grad_x"], 1e-4, 1e-5)
+    if cond_on:
+        close(c.grad, f["grad_cond"], 1e-4, 1e-5)
+    grads_close(sp, f["grads"])
+
+
+def glow_ns(d):
+    return Namespace(**d)
+
+
+def test_glowstep(golden):
+    from Flow import GlowStep
+    from tests.golden_args import GLOW_DEFAULTS
+    f = golden("glow.pt")["glowstep"]
+    gs = load_sd(GlowStep([2, 8, 4, 4], [2, 6, 4, 4], glow_ns(GLOW_DEFAULTS)), f["sd"]).train()
+    x = cu(f["x"]).requires_grad_(True)
+    c = cu(f["cond"]).requires_grad_(True)
+    y, ld = gs(x, c, torch.zeros(2, device="cuda"), False)
+    close(y, f["y"], 1e-5, 1e-5)
+    close(ld, f["logdet"], 1e-4, 1e-5)
+    ((y * cu(f["wgt"])).sum() + (ld * cu(f["gld"])).sum()).backward()
+    close(x.grad, f["grad_x"], 1e-4, 1e-5)
+    close(c.grad, f["grad_cond"], 1e-4, 1e-5)
+    grads_close(gs, f["grads"])
+    xb, ldb = gs(cu(f["y"]), cu(f["cond"]), torch.zeros(2, device="cuda"), True)
+    close(xb, f["x_back"], 1e-4, 1e-5)
+    close(ldb, f["logdet_back"], 1e-4, 1e-5)
+
+
+def test_glowstep_canonical_level0(golden):
+    from Flow import GlowStep
+    from tests.golden_args import GLOW_DEFAULTS
+    f = golden("glowstep_canonical_l0.pt")
+    a = dict(GLOW_DEFAULTS)
+    a["n_units_affine"] = 256
+    gs = load_sd(GlowStep([1, 4, 32, 32], [1, 16, 32, 32], glow_ns(a)), f["sd"]).train()
+    y, ld = gs(cu(f["x"]), cu(f["cond"]), torch.zeros(1, device="cuda"), False)
+    close(y, f["y"], 1e-4, 1e-4)
+    close(ld, f["logdet"], 1e-4, 1e-4)
+
+
+@pytest.mark.parametrize("name", ["listglow_L2K2", "listglow_L3K2_rgb_leaky_glowclamp", "listglow_uncond"])
+def test_listglow(golden, name):
+    from Flow import ListGlow
+    f = golden("glow.pt")[name]
+    args = glow_ns(f["args"])
+    # (i) first training call: data dependent init
+    flow = load_sd(ListGlow(f["x_size"], f["cond_sizes"], tuple(f["base_size"]), args), f["sd_fresh"]).train()
+    z, nll = flow.log_prob(cu(f["x"]), [cu(c) for c in f["conds"]], cu(f["base_cond"]), 0, noise=cu(f["noise_init"]))
+    close(z, f["z_init"], 1e-4, 1e-4)
+    close(nll, f["nll_init"], 1e-4, 1e-3)
+    sd_now = flow.state_dict()
+    for k, v in f["sd_init"].items():
+        if v.is_floating_point():
+            close(sd_now[k], v, 1e-4, 1e-5)
+        else:
+            assert torch.equal(sd_now[k].cpu(), v), k
+    # (ii) steady state + gradients
+    flow = load_sd(ListGlow(f["x_size"], f["cond_sizes"], tuple(f["base_size"]), args), f["sd"]).train()
+    conds = [cu(c).requires_grad_(True) for c in f["conds2"]]
+    bc = cu(f["base_cond2"]).requires_grad_(True)
+    z, nll = flow.log_prob(cu(f["x2"]), conds, bc, 0, noise=cu(f["noise2"]))
+    close(z, f["z2"], 1e-4, 1e-4)
+    close(nll, f["nll2"], 1e-4, 1e-3)
+    nll.mean().backward()
+    grads_close(flow, f["grads"], 3e-3, 3e-4)
+    for c, g in zip(conds, f["grad_conds2"]):
+        if c.numel():
+            close(c.grad, g, 1e-3, 1e-5)
+    if f["args"]["learn_prior"]:
+        close(bc.grad, f["grad_base_cond2"], 1e-3, 1e-5)
+    # (iii) reverse path with pinned draws
+    flow.eval()
+    xs = flow.sample(cu(f["z2"]), [cu(c) for c in f["conds2"]], cu(f["base_cond2"]), temperature=0.8,
+                     eps_list=[cu(e) for e in f["sample_draws"]])
+    close(xs, f["sample_from_z2"], 1e-3, 1e-4)
+
+
+def test_listglow_time_batching_equals_per_step_calls(golden):
+    """the driver's time-batched call (N = several 'timesteps' of B frames) == separate calls, frame by frame"""
+    from Flow import ListGlow
+    f = golden("glow.pt")["listglow_L2K2"]
+    flow = load_sd(ListGlow(f["x_size"], f["cond_sizes"], tuple(f["base_size"]), glow_ns(f["args"])), f["sd"]).eval()
+    g = torch.Generator().manual_seed(9)
+    B, reps = f["x_size"][0], 3
+    xs = [torch.rand(f["x_size"], generator=g) - 0.5 for _ in range(reps)]
+    cs = [[torch.randn(c, generator=g) for c in f["cond_sizes"]] for _ in range(reps)]
+    bs = [torch.randn(f["base_size"], generator=g) for _ in range(reps)]
+    ns = [torch.rand(f["x_size"], generator=g) / 256 for _ in range(reps)]
+    with torch.no_grad():
+        sep = [flow.log_prob(cu(xs[i]), [cu(c) for c in cs[i]], cu(bs[i]), 0, noise=cu(ns[i]))[1] for i in range(reps)]
+        allc = [torch.cat([cs[i][l] for i in range(reps)]) for l in range(len(f["cond_sizes"]))]
+        tog = flow.log_prob(cu(torch.cat(xs)), [cu(c) for c in allc], cu(torch.cat(bs)), 0, noise=cu(torch.cat(ns)))[1]
+    assert torch.equal(torch.cat(sep).cpu(), tog.cpu())
+
+
+@pytest.mark.parametrize("name", ["small", "seq3_4x4"])
+def test_convlstm(golden, name):
+    from Utils import ConvLSTM
+    f = golden("convlstm.pt")[name]
+    cin, hc, H, W, B, S = f["cfg"]
+    m = load_sd(ConvLSTM(cin, hc, [3, 3], bias=True, peephole=True), f["sd"])
+    x = cu(f["x"]).requires_grad_(True)
+    h0 = cu(f["h0"]).requires_grad_(True)
+    c0 = cu(f["c0"]).requires_grad_(True)
+    out, ht, ct = m(x, h0, c0)
+    close(out, f["out"], 1e-5, 1e-6)
+    close(ht, f["ht"], 1e-5, 1e-6)
+    close(ct, f["ct"], 1e-5, 1e-6)
+    ((ht * cu(f["wh"])).sum() + (ct * cu(f["wc"])).sum() + out.sum() * 0.1).backward()
+    close(x.grad, f["grad_x"], 1e-4, 1e-6)
+    close(h0.grad, f["grad_h0"], 1e-4, 1e-6)
+    close(c0.grad, f["grad_c0"], 1e-4, 1e-6)
+    grads_close(m, {k: v for k, v in f["grads"].items() if "Wc" not in k}, 1e-3, 1e-4)
+    _, htn, ctn = m(cu(f["x"]), None, None)
+    close(htn, f["ht_none"], 1e-5, 1e-6)
+    close(ctn, f["ct_none"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("name", ["plain", "smooth_resq", "overshoot_D2", "with_skip", "no_skipfeat"])
+def test_rfn_loss_end_to_end(golden, name):
+    from RFN import RFN
+    f = golden("rfn_loss.pt")[name]
+    args = Namespace(**f["args"])
+    # first call from fresh weights: ActNorm data dependent init on the t=1 batch + BatchNorm running stats
+    m = load_sd(RFN(args), f["sd_fresh"]).train()
+    out = m.loss(cu(f["x"]), 0, draws=[t for _, t in f["draws_first"]])
+    for a, b in zip(out, f["out_first"]):
+        assert abs(float(a) - b) <= 1e-4 * abs(b) + 1e-4, (float(a), b)
+    # steady state with gradients; bits/dim within 1e-4 relative (north_star)
+    m = load_sd(RFN(args), f["sd"]).train()
+    kl_fb, kl, nll = m.loss(cu(f["x"]), 0, draws=[t for _, t in f["draws"]])
+    for a, b in zip((kl_fb, kl, nll), f["out"]):
+        assert abs(float(a) - b) <= 1e-4 * abs(b) + 1e-5, (float(a), b)
+    bpd = O.bits_per_dim(kl.detach().cpu(), nll.detach().cpu(), f["x"].shape[2:], f["T"] - 1)
+    assert abs(bpd - f["bits_per_dim"]) <= 1e-4 * abs(f["bits_per_dim"])
+    (nll + 0.3 * kl_fb).backward()
+    grads_close(m, {k: v for k, v in f["grads"].items() if not k.startswith(("extractor.net.", "upscaler.net."))
+                    and "LSTMlayer.Wc" not in k}, 5e-3, 5e-4)
