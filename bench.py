@@ -1,0 +1,225 @@
+#!/usr/bin/env python3
+"""bench.py — RFN training-step throughput on synthetic SM-MNIST-shaped video (BASELINE.json metric).
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 ... bench.py --gpus N ...)
+
+One "step" = one full training iteration of the hot path as RFN/trainer.py:233-250 of the reference runs it:
+preprocess -> RFN.loss forward (extractor, ConvLSTM, latent recurrence, upscaler, time-batched Glow log_prob) ->
+backward -> gradient all-reduce (N>1) -> Adam, on the canonical SM-MNIST configuration (RFN/default_rfn_job.sh) at
+global batch 32, seq_len 20, fp32.  Inputs are resident in HBM before the timed region.  Rank 0 prints ONE JSON line.
+Strong scaling: the global batch (32 sequences) is fixed and sharded over the ranks (north_star).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+PKG = os.path.join(ROOT, "recurrent-flows-msc_amd")
+for p in (ROOT, PKG):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+PEAK_F32_MFMA_TFLOPS = 157.3   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32 dense peak
+PEAK_HBM_GBS = 8000.0
+
+
+def make_batch(B, T, seed, device):
+    from data_generators import SyntheticMovingMNIST
+    ds = SyntheticMovingMNIST(seq_len=T, seed=seed)
+    return torch.stack([ds[i] for i in range(B)]).to(device)
+
+
+def build_solver(B_local, T, device, lr=1e-4):
+    import main_rfn
+    from RFN.trainer import Solver
+    from RFN import RFN
+    from rfn_hip import dist as rdist
+    args = main_rfn.build_parser().parse_args(main_rfn.canonical_smmnist_argv(B_local, T))
+    args.path = "/gpurun_out/bench_tmp/"
+    s = Solver(args)
+    s.device = device
+    torch.manual_seed(0)
+    s.model = RFN(args).to(device).train()
+    rdist.broadcast_module_state(s.model)
+    s.reducer = rdist.GradBucketReducer(list(s.model.named_parameters()))
+    try:
+        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=lr, fused=True)
+    except Exception:
+        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=lr)
+    return s, args
+
+
+def kernel_roofline(solver, batch):
+    """one extra instrumented step: HIP events around every librfn_hip launch on its stream; group by kernel."""
+    from rfn_hip import lib
+    lib.PROFILE = []
+    solver.train_step(batch)
+    torch.cuda.synchronize()
+    rec, lib.PROFILE = lib.PROFILE, None
+    groups = {}
+    for name, meta, e0, e1 in rec:
+        ms = e0.elapsed_time(e1)
+        key = meta[1] if meta else name
+        g = groups.setdefault(key, {"calls": 0, "ms": 0.0, "flops": 0.0})
+        g["calls"] += 1
+        g["ms"] += ms
+        if meta:
+            g["flops"] += meta[2]
+    mfma = {k: v for k, v in groups.items() if v["flops"] > 0}
+    dom = max(mfma, key=lambda k: mfma[k]["ms"])
+    d = mfma[dom]
+    tot_ms = sum(v["ms"] for v in groups.values())
+    mfma_ms = sum(v["ms"] for v in mfma.values())
+    mfma_fl = sum(v["flops"] for v in mfma.values())
+    roof = {"bound": "mfma", "kernel": dom, "achieved": d["flops"] / (d["ms"] * 1e-3) / 1e12,
+            "peak": PEAK_F32_MFMA_TFLOPS, "unit": "TFLOP/s",
+            "frac": d["flops"] / (d["ms"] * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS, "traffic": None,
+            "launches": d["calls"], "avg_launch_us": 1e3 * d["ms"] / d["calls"],
+            "flops_per_launch": d["flops"] / d["calls"],
+            "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12,
+                                 "frac": mfma_fl / (mfma_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
+                                 "ms_per_step": mfma_ms, "flops_per_step": mfma_fl},
+            "hip_kernel_ms_per_step": tot_ms}
+    table = sorted(([k, v["calls"], round(v["ms"], 3), round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)]
+                    for k, v in groups.items()), key=lambda r: -r[2])
+    return roof, table
+
+
+def cpu_baseline(T_cpu=4, B_cpu=2):
+    """the CPU port (oracle) timed on this box's host cores: forward + backward + Adam of the SAME canonical
+    architecture on a bounded sample (B_cpu sequences x T_cpu frames)."""
+    import main_rfn
+    from RFN import RFN
+    from oracle import rfn_oracle as O
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    args = main_rfn.build_parser().parse_args(main_rfn.canonical_smmnist_argv(B_cpu, T_cpu))
+    torch.manual_seed(0)
+    sd = {k: v.detach().clone() for k, v in RFN(args).state_dict().items()}  # parameter container only (CPU)
+    leaves = []
+    for k, v in sd.items():
+        if v.is_floating_point() and "running_" not in k:
+            v.requires_grad_(True)
+            leaves.append(v)
+    opt = torch.optim.Adam(leaves, lr=1e-4)
+    x = make_batch(B_cpu, T_cpu, 7, "cpu") * 255 / 256 - 0.5
+    cfg = vars(args)
+    O.rfn_loss(sd, cfg, x, None, True)  # warm-up = ActNorm init
+    t0 = time.perf_counter()
+    reps = 0
+    while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+        kl_fb, kl, nll = O.rfn_loss(sd, cfg, x, None, True)
+        opt.zero_grad()
+        (nll + kl_fb).backward()
+        opt.step()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": B_cpu * T_cpu / dt, "unit": "frames/s", "cores": cores, "kind": "port",
+            "sample": "oracle (CPU restatement of the reference, torch fp32) fwd+bwd+Adam, canonical SM-MNIST model, "
+                      "B=%d T=%d, mean of %d steps" % (B_cpu, T_cpu, reps)}
+
+
+def parity_check(device):
+    """GPU loss vs CPU oracle on the canonical architecture, same weights and noise (B=2, T=3)."""
+    import main_rfn
+    from RFN import RFN
+    from oracle import rfn_oracle as O
+    B, T = 2, 3
+    args = main_rfn.build_parser().parse_args(main_rfn.canonical_smmnist_argv(B, T))
+    torch.manual_seed(1)
+    m = RFN(args).to(device).train()
+    g = torch.Generator().manual_seed(2)
+    x = make_batch(B, T, 11, "cpu") * 255 / 256 - 0.5
+    draws = []
+    for _ in range(T - 1):
+        draws += [torch.randn(B, 56, 2, 2, generator=g), torch.randn(B, 56, 2, 2, generator=g),
+                  torch.rand(B, 1, 64, 64, generator=g) / 256]
+    with torch.no_grad():
+        m.loss(x.to(device), 0, draws=draws)
+        kl_fb, kl, nll = m.loss(x.to(device), 0, draws=draws)
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        r = O.rfn_loss(sd, vars(args), x, draws, True)
+    bpd_gpu = O.bits_per_dim(kl.cpu(), nll.cpu(), x.shape[2:], T - 1)
+    bpd_ref = O.bits_per_dim(r[1], r[2], x.shape[2:], T - 1)
+    return {"bits_per_dim_gpu": bpd_gpu, "bits_per_dim_oracle": bpd_ref,
+            "rel_err": abs(bpd_gpu - bpd_ref) / abs(bpd_ref)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=32, help="GLOBAL batch (sequences)")
+    ap.add_argument("--frames", type=int, default=20)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-roofline", action="store_true")
+    a = ap.parse_args()
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local = int(os.environ.get("LOCAL_RANK", 0))
+    assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    torch.cuda.set_device(local)
+    device = torch.device("cuda", local)
+    if world > 1:
+        dist.init_process_group("nccl")
+    assert a.batch % world == 0, "global batch must divide over ranks"
+    B_local = a.batch // world
+
+    solver, args = build_solver(B_local, a.frames, device)
+    batches = [make_batch(B_local, a.frames, 100 + rank * 17 + i, device) for i in range(2)]
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for i in range(max(a.warmup, 1)):
+        solver.train_step(batches[i % 2])
+    barrier()
+    t0 = time.perf_counter()
+    for i in range(a.steps):
+        solver.train_step(batches[i % 2])
+    barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=device, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t)
+    ms_per_step = 1e3 * dt / a.steps
+    frames_per_s = a.batch * a.frames * a.steps / dt
+    bpd = solver.bits[-1]
+
+    out = {"metric": "frames/sec, RFN SM-MNIST 64x64 train step (fwd+bwd+Adam)", "value": frames_per_s,
+           "unit": "frames/s", "n_gpus": world, "steps": a.steps, "warmup": a.warmup, "ms_per_step": ms_per_step,
+           "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "RFN SM-MNIST 64x64 canonical (K=10 L=5 Hd=256 h=200 z=56), global_batch=%d, "
+                                  "seq_len=%d, train step" % (a.batch, a.frames),
+                      "global_batch": a.batch, "seq_len": a.frames, "parallelism": "dp%d" % world},
+           "modeled_frames_per_s": a.batch * (a.frames - 1) * a.steps / dt, "bits_per_dim_last_step": bpd}
+    if rank == 0 and world == 1:
+        if not a.no_roofline:
+            roof, table = kernel_roofline(solver, batches[0])
+            out["roofline"] = roof
+            os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
+            with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_table.json"), "w") as f:
+                json.dump({"columns": ["kernel", "launches", "ms_per_step", "GFLOP/s"], "rows": table}, f, indent=1)
+        out["parity"] = parity_check(device)
+        if not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

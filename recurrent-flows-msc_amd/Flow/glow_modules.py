@@ -187,7 +187,9 @@ class InvConv(nn.Module):
             lower, u = self.matrices()
             dlogdet = torch.sum(self.log_s) * h * w
             if reverse:
-                weight = torch.matmul(torch.inverse(u), torch.matmul(torch.inverse(lower), torch.inverse(self.p)))
+                # U⁻¹ L⁻¹ P⁻¹ (glow_modules.py:198-203) by two triangular solves; P is a permutation, P⁻¹ = Pᵀ
+                weight = torch.linalg.solve_triangular(
+                    u, torch.linalg.solve_triangular(lower, self.p.t(), upper=False, unitriangular=True), upper=True)
             else:
                 weight = torch.matmul(self.p, torch.matmul(lower, u))
         return weight, dlogdet

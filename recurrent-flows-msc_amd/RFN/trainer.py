@@ -1,0 +1,204 @@
+"""Solver — training driver with the reference's surface (RFN/trainer.py of the reference): `Solver(args).build();
+.train(); .load(ckpt)`, `preprocess`, `compute_loss` (bits/dim bookkeeping), β annealing, linear LR decay, checkpoint
+dict layout.  Plotting (matplotlib PNG panels) and the file-backed datasets are outside the hot-path scope; a synthetic
+SM-MNIST-shaped loader is built in (`--synthetic_data`).  Multi-GPU = one process per GPU (rfn_hip/dist.py)."""
+import math
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+from torch.utils.data import DataLoader
+
+from data_generators import SyntheticMovingMNIST
+from rfn_hip import dist as rdist
+from Utils import set_gpu
+from .RFN_new import RFN
+
+
+class EarlyStopping:
+    """RFN/trainer.py:18-44."""
+
+    def __init__(self, min_delta=0, patience=50, verbose=True):
+        self.min_delta, self.patience, self.verbose = min_delta, patience, verbose
+        self.wait, self.best_loss, self.stop_training = 0, 1e15, False
+
+    def step(self, epoch, loss):
+        if loss is None:
+            return False
+        if (loss - self.best_loss) < -self.min_delta:
+            self.best_loss, self.wait = loss, 1
+            return False
+        if self.wait >= self.patience:
+            self.stop_training = True
+            if self.verbose:
+                print("STOP! Criterion met at epoch %d" % epoch)
+            return True
+        self.wait += 1
+        return False
+
+
+class Solver(object):
+    def __init__(self, args):
+        self.args = args
+        for k in ("n_bits", "n_epochs", "learning_rate", "verbose", "batch_size", "patience_lr", "factor_lr", "min_lr",
+                  "patience_es", "beta_max", "beta_min", "beta_steps", "choose_data", "n_frames", "digit_size",
+                  "step_length", "num_digits", "image_size", "preprocess_range", "preprocess_scale", "num_workers",
+                  "multigpu", "n_predictions", "n_conditions", "scheduler_type", "use_validation_set"):
+            setattr(self, k, getattr(args, k))
+        self.path = str(os.path.abspath(os.getcwd())) + args.path
+        self.plot_counter, self.epoch_i, self.counter = 0, 0, 0
+        self.losses, self.kl_loss, self.recon_loss, self.bits = [], [], [], []
+        self.best_loss, self.beta, self.stop = 1e15, args.beta_min, False
+        self.rank = int(os.environ.get("RANK", 0))
+        self.world = int(os.environ.get("WORLD_SIZE", 1))
+        self.device = set_gpu(True)
+
+    # ---------------------------------------------------------------------------------------------- setup
+    def build(self):
+        if self.multigpu and self.world > 1 and not dist.is_initialized():
+            local = int(os.environ.get("LOCAL_RANK", 0))
+            if torch.cuda.is_available():
+                torch.cuda.set_device(local)
+                self.device = torch.device("cuda", local)
+            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+        self.train_loader, self.test_loader = self.create_loaders()
+        if self.rank == 0:
+            os.makedirs(self.path + "png_folder", exist_ok=True)
+            os.makedirs(self.path + "model_folder", exist_ok=True)
+        self.model = RFN(self.args).to(self.device)
+        rdist.broadcast_module_state(self.model)
+        self.reducer = rdist.GradBucketReducer(list(self.model.named_parameters()))
+        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate)
+        self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", patience=self.patience_lr,
+                                                                    factor=self.factor_lr, min_lr=self.min_lr)
+        self.earlystopping = EarlyStopping(min_delta=0, patience=self.patience_es, verbose=self.verbose)
+        self.counter, self.stop = 0, False
+
+    def create_loaders(self):
+        if not getattr(self.args, "synthetic_data", False):
+            raise RuntimeError("the file-backed datasets of the reference (MNIST download, BAIR, KTH) are outside this "
+                               "implementation's scope; pass --synthetic_data for SM-MNIST-shaped synthetic video")
+        c = self.args.x_dim[1]
+        mk = lambda seed: SyntheticMovingMNIST(seq_len=self.n_frames, image_size=self.image_size,
+                                               digit_size=self.digit_size, num_digits=self.num_digits,
+                                               step_length=self.step_length, channels=c,
+                                               seed=seed * self.world + self.rank)
+        kw = dict(batch_size=self.batch_size, num_workers=self.num_workers, shuffle=True, drop_last=True)
+        return DataLoader(mk(0), **kw), DataLoader(mk(1), **kw)
+
+    # ---------------------------------------------------------------------------------------------- arithmetic
+    def preprocess(self, x, reverse=False):
+        """RFN/trainer.py:165-188."""
+        n_bins = 2 ** self.n_bits
+        if not reverse:
+            x = x * self.preprocess_scale
+            if self.n_bits < 8:
+                x = torch.floor(x / 2 ** (8 - self.n_bits))
+            x = x / n_bins
+            return x - 0.5 if self.preprocess_range == "0.5" else x
+        if self.preprocess_range == "0.5":
+            x = x + 0.5
+        x = x * n_bins
+        return torch.clamp(torch.floor(x) * (256. / n_bins), 0, 255).byte()
+
+    def adjust_learning_rate(self, batch):
+        """RFN/trainer.py:190-204 — linear decay to zero over 150k steps after step 100k."""
+        startbatch, num_steps = 100000, 150000
+        if batch > startbatch:
+            lr = self.learning_rate - (batch - startbatch) * self.learning_rate / num_steps
+            for g in self.optimizer.param_groups:
+                g["lr"] = lr
+        if batch == (startbatch + num_steps - 5):
+            self.stop = True
+
+    def compute_loss(self, nll, kl_free_bit, kl, dims, t=10):
+        """RFN/trainer.py:206-219 — loss = nll + β·kl_fb ; bits/dim = (kl+nll)/(ln2 · C·H·W · t)."""
+        loss = nll + self.beta * kl_free_bit
+        kl_store, nll_store = kl.detach(), nll.detach()
+        bits = (kl_store + nll_store) / (np.log(2.) * float(np.prod(list(dims))) * t)
+        self.bits.append(float(bits))
+        self.losses.append(float(loss.detach()) / t)
+        self.kl_loss.append(float(kl_store) / t)
+        self.recon_loss.append(float(nll_store) / t)
+        return loss
+
+    # ---------------------------------------------------------------------------------------------- loop
+    def train_step(self, image):
+        """one optimizer step on an already-resident [B,T,C,H,W] batch in [0,1] (RFN/trainer.py:237-250)."""
+        image = self.preprocess(image)
+        self.beta = min(self.beta_max, self.beta_min + self.counter * (self.beta_max - self.beta_min) / self.beta_steps)
+        first = self.counter == 0 and self.world > 1
+        kl_free_bit, kl, nll = self.model.loss(image, 0)
+        if first:  # replicas must share rank 0's data dependent ActNorm init: broadcast, then redo the step's forward
+            rdist.broadcast_module_state(self.model)
+            kl_free_bit, kl, nll = self.model.loss(image, 0)
+        loss = self.compute_loss(nll, kl_free_bit, kl, image.shape[2:], t=image.shape[1] - 1)
+        self.optimizer.zero_grad(set_to_none=True)
+        loss.backward()
+        self.reducer.finish()
+        self.optimizer.step()
+        if self.scheduler_type == "linear":
+            self.adjust_learning_rate(self.counter)
+        self.counter += 1
+        return loss
+
+    def train(self):
+        max_steps = getattr(self.args, "max_steps", 0)
+        for _ in range(self.n_epochs):
+            self.model.train()
+            self.epoch_i += 1
+            for image in self.train_loader:
+                image = image[0] if self.choose_data == "bair" and isinstance(image, (list, tuple)) else image
+                self.train_step(image.to(self.device, non_blocking=True))
+                if max_steps and self.counter >= max_steps:
+                    self.stop = True
+                    break
+            epoch_loss = float(np.mean(self.losses)) if self.losses else math.nan
+            if self.rank == 0:
+                self.checkpoint("rfn.pt", self.epoch_i, epoch_loss)
+            stop = self.earlystopping.step(self.epoch_i, epoch_loss)
+            if stop or self.stop:
+                break
+            if self.earlystopping.best_loss < self.best_loss and self.epoch_i > 50 and self.rank == 0:
+                self.best_loss = self.earlystopping.best_loss
+                self.checkpoint("rfn_best_model.pt", self.epoch_i, epoch_loss)
+            if self.scheduler_type == "plateau":
+                self.scheduler.step(epoch_loss)
+            if self.verbose:
+                print("Epoch {} Loss: {:.2f}".format(self.epoch_i, epoch_loss))
+            elif self.rank == 0:
+                self.status()
+
+    # ---------------------------------------------------------------------------------------------- state
+    def checkpoint(self, model_name, epoch, loss):
+        """same dict layout as RFN/trainer.py:277-300 (model/optimizer state, histories, counters, args)."""
+        common = {"epoch": epoch, "loss": loss, "kl_loss": self.kl_loss, "recon_loss": self.recon_loss,
+                  "losses": self.losses, "bits_per_dim": self.bits, "annealing_counter": self.counter,
+                  "args": self.args}
+        full = dict(common)
+        full.update({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+                     "plot_counter": self.plot_counter})
+        torch.save(full, self.path + "model_folder/" + model_name)
+        torch.save(common, self.path + "model_folder/eval_dict.pt")
+
+    def load(self, load_model):
+        self.model.load_state_dict(load_model["model_state_dict"])
+        self.optimizer.load_state_dict(load_model["optimizer_state_dict"])
+        self.epoch_i += load_model["epoch"]
+        loss = load_model["loss"]
+        self.kl_loss, self.recon_loss = load_model["kl_loss"], load_model["recon_loss"]
+        self.losses, self.plot_counter = load_model["losses"], load_model["plot_counter"]
+        self.counter, self.bits = load_model["annealing_counter"], load_model["bits_per_dim"]
+        self.best_loss = loss
+        self.model.to(self.device)
+        return self.epoch_i, loss
+
+    def status(self):
+        lr = self.optimizer.param_groups[0]["lr"]
+        with open(self.path + "model_folder/status.txt", "a") as f:
+            print("STATUS:", file=f)
+            if self.kl_loss:
+                print("\tKL and Reconstruction loss: {:.4f}, {:.4f}".format(self.kl_loss[-1], self.recon_loss[-1]),
+                      file=f)
+            print(f"\tEpoch {self.epoch_i}, Beta value {self.beta:.4f}, Learning rate {lr}", file=f)

@@ -1,0 +1,124 @@
+"""Data parallelism for the RFN training step: one process per GPU, the sequence batch sharded on dim 0, gradients
+all-reduced with RCCL over xGMI (torch.distributed backend "nccl" IS RCCL on ROCm; "gloo" is used by the CPU tests).
+
+The reference has no working multi-GPU path (its nn.DataParallel wrapper is broken and bypassed), so
+the contract here is "same mathematics as one process running the global batch":
+  * shared parameters are broadcast from rank 0 at start and their gradients are averaged every step;
+  * the batch-shaped learnable initial states (z_0, z_0x, h_0, c_0, a_0, ca_0 — RFN_new.py:69-76) are SHARDED: each
+    rank owns the rows of its local sequences, so they are never reduced;
+  * data dependent ActNorm initialisation happens on rank 0's first batch and is broadcast (`sync_buffers_and_init`);
+  * gradient buckets are reduced asynchronously while backward is still running (flow parameters become ready first),
+    in a few large buckets: xGMI is point-to-point, fewer / larger collectives amortise the per-link latency.
+"""
+import torch
+import torch.distributed as dist
+
+SHARDED_PARAM_NAMES = ("z_0", "z_0x", "h_0", "c_0", "a_0", "ca_0")
+
+
+def is_dist():
+    return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
+
+
+class GradBucketReducer:
+    """Flat-bucket asynchronous gradient averaging driven by post-accumulate-grad hooks."""
+
+    def __init__(self, named_params, bucket_bytes=64 << 20, group=None, sharded_names=SHARDED_PARAM_NAMES):
+        self.group = group
+        self.world = dist.get_world_size(group) if is_dist() else 1
+        # top-level batch-shaped initial states are sharded over ranks, everything else is replicated
+        params = [(n, p) for n, p in named_params if p.requires_grad and not ("." not in n and n in sharded_names)]
+        self.params = [p for _, p in params]
+        self.names = [n for n, _ in params]
+        # buckets in REVERSE registration order: backward produces gradients roughly last-layer-first
+        self.buckets, cur, cur_bytes = [], [], 0
+        for p in reversed(self.params):
+            cur.append(p)
+            cur_bytes += p.numel() * p.element_size()
+            if cur_bytes >= bucket_bytes:
+                self.buckets.append(cur)
+                cur, cur_bytes = [], 0
+        if cur:
+            self.buckets.append(cur)
+        self._bucket_of = {}
+        for bi, b in enumerate(self.buckets):
+            for p in b:
+                self._bucket_of[id(p)] = bi
+        self._pending = [0] * len(self.buckets)
+        self._works = []
+        self._flat = [None] * len(self.buckets)
+        self._hooks = []
+        if self.world > 1:
+            for p in self.params:
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
+        self.reset()
+
+    def reset(self):
+        self._pending = [len(b) for b in self.buckets]
+        self._works = []
+
+    def _launch(self, bi):
+        b = self.buckets[bi]
+        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
+        flat = torch.cat([g.reshape(-1) for g in grads])
+        work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._flat[bi] = flat
+        self._works.append((bi, work))
+
+    def _on_grad(self, p):
+        bi = self._bucket_of[id(p)]
+        self._pending[bi] -= 1
+        if self._pending[bi] == 0:
+            self._launch(bi)
+
+    def finish(self):
+        """call after backward(): flush buckets whose parameters got no gradient, wait, write averages back."""
+        if self.world == 1:
+            return
+        for bi, n in enumerate(self._pending):
+            if n > 0:
+                self._pending[bi] = 0
+                self._launch(bi)
+        for bi, work in self._works:
+            work.wait()
+            flat = self._flat[bi]
+            flat.div_(self.world)
+            off = 0
+            for p in self.buckets[bi]:
+                n = p.numel()
+                g = flat[off:off + n].view_as(p)
+                if p.grad is None:
+                    p.grad = g.clone()
+                else:
+                    p.grad.copy_(g)
+                off += n
+            self._flat[bi] = None
+        self.reset()
+
+
+def broadcast_module_state(module, src=0, group=None, sharded_names=SHARDED_PARAM_NAMES):
+    """parameters (except the sharded batch-shaped ones) and buffers <- rank `src`."""
+    if not is_dist():
+        return
+    with torch.no_grad():
+        for n, p in module.named_parameters():
+            if "." not in n and n in sharded_names:
+                continue
+            dist.broadcast(p.data, src=src, group=group)
+        for _, b in module.named_buffers():
+            if b.dtype == torch.uint8:  # ActNorm.initialized flags
+                t = b.to(torch.int32)
+                dist.broadcast(t, src=src, group=group)
+                b.copy_(t.to(torch.uint8))
+            else:
+                dist.broadcast(b, src=src, group=group)
+
+
+def all_reduce_mean_scalars(*vals, group=None):
+    """average a few 0-d loss tensors over ranks for logging."""
+    if not is_dist():
+        return [float(v) for v in vals]
+    t = torch.stack([v.detach().float().reshape(()) for v in vals])
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    t /= dist.get_world_size(group)
+    return [float(x) for x in t]

@@ -70,11 +70,24 @@ def load():
     return lib
 
 
-def call(name, *args):
+# Optional in-process kernel timing (bench.py): when PROFILE is a list, every call is bracketed by HIP events recorded
+# on the stream the kernel is launched on, and (name, meta, start_event, end_event) is appended.
+PROFILE = None
+
+
+def call(name, *args, meta=None):
     """Invoke an int-returning entry point on the current torch stream; raise on a non-zero code."""
     lib = load()
-    stream = ctypes.c_void_p(torch.cuda.current_stream().cuda_stream)
-    rc = getattr(lib, name)(*args, stream)
+    cur = torch.cuda.current_stream()
+    stream = ctypes.c_void_p(cur.cuda_stream)
+    if PROFILE is not None:
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(cur)
+        rc = getattr(lib, name)(*args, stream)
+        e1.record(cur)
+        PROFILE.append((name, meta, e0, e1))
+    else:
+        rc = getattr(lib, name)(*args, stream)
     if rc != 0:
         raise RuntimeError("%s failed (code %d): %s" % (name, rc, lib.rfn_last_error().decode()))
 
