@@ -211,7 +211,7 @@ def main():
             out["roofline"] = roof
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_table.json"), "w") as f:
-                json.dump({"columns": ["kernel", "launches", "ms_per_step", "GFLOP/s"], "rows": table}, f, indent=1)
+                json.dump({"columns": ["kernel", "launches", "ms_per_step", "TFLOP/s"], "rows": table}, f, indent=1)
         out["parity"] = parity_check(device)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
