@@ -55,14 +55,10 @@ def build_solver(B_local, T, device, lr=1e-4):
     return s, args
 
 
-def kernel_roofline(solver, batch):
-    """one extra instrumented step: HIP events around every librfn_hip launch on its stream; group by kernel."""
-    from rfn_hip import lib
-    lib.PROFILE = []
-    solver.train_step(batch)
-    torch.cuda.synchronize()
-    rec, lib.PROFILE = lib.PROFILE, None
-    groups = {}
+def kernel_roofline(rec, steps):
+    """`rec` = (name, meta, start, end) HIP-event pairs recorded on the launch stream around every librfn_hip launch
+    of the K timed steps (rfn_hip.lib.PROFILE); grouped by kernel symbol."""
+    groups, shapes = {}, {}
     for name, meta, e0, e1 in rec:
         ms = e0.elapsed_time(e1)
         key = meta[1] if meta else name
@@ -71,6 +67,10 @@ def kernel_roofline(solver, batch):
         g["ms"] += ms
         if meta:
             g["flops"] += meta[2]
+            h = shapes.setdefault(meta[1] + " | " + meta[3], {"calls": 0, "ms": 0.0, "flops": 0.0})
+            h["calls"] += 1
+            h["ms"] += ms
+            h["flops"] += meta[2]
     mfma = {k: v for k, v in groups.items() if v["flops"] > 0}
     dom = max(mfma, key=lambda k: mfma[k]["ms"])
     d = mfma[dom]
@@ -84,11 +84,14 @@ def kernel_roofline(solver, batch):
             "flops_per_launch": d["flops"] / d["calls"],
             "all_mfma_kernels": {"achieved": mfma_fl / (mfma_ms * 1e-3) / 1e12,
                                  "frac": mfma_fl / (mfma_ms * 1e-3) / 1e12 / PEAK_F32_MFMA_TFLOPS,
-                                 "ms_per_step": mfma_ms, "flops_per_step": mfma_fl},
-            "hip_kernel_ms_per_step": tot_ms}
-    table = sorted(([k, v["calls"], round(v["ms"], 3), round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)]
-                    for k, v in groups.items()), key=lambda r: -r[2])
-    return roof, table
+                                 "ms_per_step": mfma_ms / steps, "flops_per_step": mfma_fl / steps},
+            "hip_kernel_ms_per_step": tot_ms / steps}
+    table = sorted(([k, v["calls"] // steps, round(v["ms"] / steps, 3),
+                     round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)] for k, v in groups.items()), key=lambda r: -r[2])
+    shape_rows = sorted(([k, v["calls"] // steps, round(v["ms"] / steps, 3),
+                          round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2)] for k, v in shapes.items()),
+                        key=lambda r: -r[2])
+    return roof, {"kernels": table, "shapes": shape_rows}
 
 
 def cpu_baseline(T_cpu=4, B_cpu=2):
@@ -97,8 +100,13 @@ def cpu_baseline(T_cpu=4, B_cpu=2):
     import main_rfn
     from RFN import RFN
     from oracle import rfn_oracle as O
-    cores = os.cpu_count() or 1
+    try:
+        cores = len(os.sched_getaffinity(0))
+    except AttributeError:
+        cores = os.cpu_count() or 1
+    cores = max(1, min(cores, 16))  # the GPU box grants 16 host cores per GPU
     torch.set_num_threads(cores)
+    print("[bench] cpu_baseline on %d host threads ..." % cores, file=sys.stderr, flush=True)
     args = main_rfn.build_parser().parse_args(main_rfn.canonical_smmnist_argv(B_cpu, T_cpu))
     torch.manual_seed(0)
     sd = {k: v.detach().clone() for k, v in RFN(args).state_dict().items()}  # parameter container only (CPU)
@@ -113,12 +121,13 @@ def cpu_baseline(T_cpu=4, B_cpu=2):
     O.rfn_loss(sd, cfg, x, None, True)  # warm-up = ActNorm init
     t0 = time.perf_counter()
     reps = 0
-    while reps < 2 or (time.perf_counter() - t0 < 10.0 and reps < 8):
+    while reps < 1 or (time.perf_counter() - t0 < 10.0 and reps < 8):
         kl_fb, kl, nll = O.rfn_loss(sd, cfg, x, None, True)
         opt.zero_grad()
         (nll + kl_fb).backward()
         opt.step()
         reps += 1
+        print("[bench] cpu_baseline rep %d: %.1f s" % (reps, time.perf_counter() - t0), file=sys.stderr, flush=True)
     dt = (time.perf_counter() - t0) / reps
     return {"value": B_cpu * T_cpu / dt, "unit": "frames/s", "cores": cores, "kind": "port",
             "sample": "oracle (CPU restatement of the reference, torch fp32) fwd+bwd+Adam, canonical SM-MNIST model, "
@@ -182,14 +191,21 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    from rfn_hip import lib as rlib
     for i in range(max(a.warmup, 1)):
         solver.train_step(batches[i % 2])
+    profile = rank == 0 and world == 1 and not a.no_roofline
     barrier()
+    if profile:
+        rlib.PROFILE = []  # HIP events on the launch stream around every librfn_hip launch of the timed region
     t0 = time.perf_counter()
     for i in range(a.steps):
         solver.train_step(batches[i % 2])
     barrier()
     dt = time.perf_counter() - t0
+    rec, rlib.PROFILE = rlib.PROFILE, None
+    if rank == 0:
+        print("[bench] timed region done: %.1f ms/step" % (1e3 * dt / a.steps), file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -206,12 +222,13 @@ def main():
                       "global_batch": a.batch, "seq_len": a.frames, "parallelism": "dp%d" % world},
            "modeled_frames_per_s": a.batch * (a.frames - 1) * a.steps / dt, "bits_per_dim_last_step": bpd}
     if rank == 0 and world == 1:
-        if not a.no_roofline:
-            roof, table = kernel_roofline(solver, batches[0])
+        if profile:
+            roof, table = kernel_roofline(rec, a.steps)
             out["roofline"] = roof
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_table.json"), "w") as f:
-                json.dump({"columns": ["kernel", "launches", "ms_per_step", "TFLOP/s"], "rows": table}, f, indent=1)
+                json.dump({"columns": ["kernel", "launches_per_step", "ms_per_step", "TFLOP/s"],
+                           "rows": table["kernels"], "by_shape": table["shapes"]}, f, indent=1)
         out["parity"] = parity_check(device)
         if not a.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()

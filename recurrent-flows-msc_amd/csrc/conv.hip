@@ -33,6 +33,8 @@ struct ConvParams {
     const float* p1;
     int TWp, TH, TF, tw_shift, th_shift;
     int n_wtiles, n_htiles, n_ftiles;
+    int P2, P2_shift;  // (unused by the forward kernel; kept for layout compatibility)
+    int ksplit;        // gridDim.z: the K (input channel chunk) range is split over z, partial sums meet by atomicAdd
 };
 
 // packed weight index: (((g8*T + tap)*2 + kk)*CoutP + co)*4 + ks   <->  cin = g8*8 + 2*ks + kk
@@ -142,6 +144,61 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
 
+    // ---- staging descriptors, computed ONCE per workgroup (the integer divisions live here, not in the K loop):
+    // thread -> image slot(s) r = slot + P2*j and channel phase; per chunk it then only adds a channel offset.
+    // P2 = slots per pass (compile time): a 1x1 tile of 128 pixels is covered by half the block, so the two halves
+    // take alternate channels (GROUPS = 2); every other case has IMG > 128 and uses all 256 threads as slots.
+    constexpr int BPX = 32 * TPX * WPX;
+    constexpr int NPOS = (KS == 1) ? 1 : (BPX >= 256 ? 4 : 2);
+    constexpr int GROUPS = (KS == 1 && BPX == 128) ? 2 : 1;
+    constexpr int P2 = 256 / GROUPS;
+    const int slot = tid & (P2 - 1);
+    const int phase = __builtin_amdgcn_readfirstlane(tid / P2);  // wave-uniform: keeps channel math scalar
+    int soff1[NPOS], soff2[NPOS];
+    bool sok[NPOS], sin[NPOS];
+#pragma unroll
+    for (int j = 0; j < NPOS; ++j) {
+        const int r = slot + P2 * j;
+        sin[j] = r < IMG;
+        const int f = r / FRM;
+        const int rr = r - f * FRM;
+        const int yy = rr / RW;
+        const int xx = rr - yy * RW;
+        const int gy = y0 + yy - PAD, gx = x0 + xx - PAD;
+        sok[j] = sin[j] && (f0 + f < p.N) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        // invalid slots read element 0 of the channel plane (always mapped) and are zeroed after the load, so the
+        // loads below are unconditional and the compiler can keep all of them in flight (no per-load branch/wait)
+        soff1[j] = sok[j] ? (int)(f * p.in1_ns) + gy * p.W + gx : 0;
+        soff2[j] = sok[j] ? (int)(f * p.in2_ns) + gy * p.W + gx : 0;
+    }
+    const float* in1b = p.in1 + (long)f0 * p.in1_ns;
+    const float* in2b = p.in2 ? p.in2 + (long)f0 * p.in2_ns : p.in1;
+    float stg[KC / GROUPS][NPOS];
+    auto prefetch = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < KC / GROUPS; ++i) {
+            const int ch = chunk * KC + phase + GROUPS * i;  // scalar
+            const bool chv = ch < Cin;
+            const int chc = chv ? ch : 0;
+            const bool first = chc < p.C1;
+            const float* src = first ? in1b + (long)chc * HW : in2b + (long)(chc - p.C1) * HW;
+#pragma unroll
+            for (int j = 0; j < NPOS; ++j) {
+                const float v = src[first ? soff1[j] : soff2[j]];
+                stg[i][j] = (sok[j] && chv) ? v : 0.f;
+            }
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int i = 0; i < KC / GROUPS; ++i) {
+            const int c = phase + GROUPS * i;
+#pragma unroll
+            for (int j = 0; j < NPOS; ++j)
+                if (sin[j]) lds[c * IMG + slot + P2 * j] = stg[i][j];
+        }
+    };
+
     const int total_it = p.Cin8 * T;
     const f32x4* wp4 = reinterpret_cast<const f32x4*>(p.wpk);
     // A fragment of iteration `it` for cout tile a:  wp4[(it*2 + kk)*CoutP + co_base + a*32 + l31]
@@ -149,29 +206,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
 #pragma unroll
     for (int a = 0; a < TCO; ++a) a_cur[a] = wp4[((long)0 * 2 + kk) * p.CoutP + co_base + a * 32 + l31];
 
-    const int nchunks = (p.Cin8 * 8 + KC - 1) / KC;
-    for (int chunk = 0; chunk < nchunks; ++chunk) {
-        __syncthreads();
-        // ---- stage KC channels of the haloed tile (zero outside the image / past Cin / past N)
-        const int cb = chunk * KC;
-        for (int idx = tid; idx < KC * IMG; idx += 256) {
-            int c = idx / IMG;
-            int r = idx - c * IMG;
-            int f = r / FRM;
-            int rr = r - f * FRM;
-            int yy = rr / RW;
-            int xx = rr - yy * RW;
-            int gy = y0 + yy - PAD, gx = x0 + xx - PAD, n = f0 + f, ch = cb + c;
-            float v = 0.f;
-            if (ch < Cin && n < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                if (ch < p.C1)
-                    v = p.in1[n * p.in1_ns + (long)ch * HW + gy * p.W + gx];
-                else
-                    v = p.in2[n * p.in2_ns + (long)(ch - p.C1) * HW + gy * p.W + gx];
+    // epilogue parameters of this block's BCO channels -> LDS (read after the K loop; its barriers order the write)
+    float* ep = lds + KC * IMG;  // [2][BCO]
+    if (p.ep_mode != 0) {
+        for (int c = tid; c < BCO; c += 256) {
+            const int co = blockIdx.y * BCO + c;
+            float e0 = 0.f, e1 = 1.f;
+            if (co < p.Cout) {
+                e0 = p.p0[co];
+                if (p.ep_mode == 1) e1 = expf(p.p1[co]);
+                if (p.ep_mode == 2) e1 = expf(3.f * p.p1[co]);
             }
-            lds[idx] = v;
+            ep[c] = e0;
+            ep[BCO + c] = e1;
         }
+    }
+
+    const int nchunks_all = (p.Cin8 * 8 + KC - 1) / KC;
+    const int cps = (nchunks_all + p.ksplit - 1) / p.ksplit;  // chunks per K split
+    const int chunk0 = blockIdx.z * cps;
+    const int nchunks = chunk0 + cps < nchunks_all ? chunk0 + cps : nchunks_all;
+    if (p.ksplit > 1) {
+#pragma unroll
+        for (int a = 0; a < TCO; ++a)
+            a_cur[a] = wp4[((long)(chunk0 * (KC / 8) * T) * 2 + kk) * p.CoutP + co_base + a * 32 + l31];
+    }
+    if (chunk0 < nchunks) prefetch(chunk0);
+    for (int chunk = chunk0; chunk < nchunks; ++chunk) {
+        __syncthreads();  // every wave is done reading the previous chunk
+        commit();
         __syncthreads();
+        if (chunk + 1 < nchunks) prefetch(chunk + 1);  // global loads stay in flight under the MFMAs below
 #pragma unroll
         for (int s8 = 0; s8 < KC / 8; ++s8) {
             const int g8 = chunk * (KC / 8) + s8;
@@ -187,18 +252,33 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                         a_nxt[a] = wp4[((long)(it + 1) * 2 + kk) * p.CoutP + co_base + a * 32 + l31];
                 }
                 const int tapoff = (tap / KS) * RW + (tap % KS);
+                const float* lbase = lds + (s8 * 8 + kk) * IMG + tapoff;
+                if (nks == 4) {  // full group: no per-k-step branches, LDS reads free to run ahead of the MFMAs
 #pragma unroll
-                for (int ks = 0; ks < 4; ++ks) {
-                    if (ks < nks) {
-                        const float* lrow = lds + (s8 * 8 + 2 * ks + kk) * IMG + tapoff;
+                    for (int ks = 0; ks < 4; ++ks) {
                         float b[TPX];
 #pragma unroll
-                        for (int t = 0; t < TPX; ++t) b[t] = lrow[lds_off[t]];
+                        for (int t = 0; t < TPX; ++t) b[t] = lbase[2 * ks * IMG + lds_off[t]];
 #pragma unroll
                         for (int a = 0; a < TCO; ++a)
 #pragma unroll
                             for (int t = 0; t < TPX; ++t)
                                 acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][ks], b[t], acc[a][t], 0, 0, 0);
+                    }
+                } else {         // ragged tail of Cin (at most once per tap)
+#pragma unroll
+                    for (int ks = 0; ks < 3; ++ks) {
+                        if (ks < nks) {
+                            float b[TPX];
+#pragma unroll
+                            for (int t = 0; t < TPX; ++t) b[t] = lbase[2 * ks * IMG + lds_off[t]];
+#pragma unroll
+                            for (int a = 0; a < TCO; ++a)
+#pragma unroll
+                                for (int t = 0; t < TPX; ++t)
+                                    acc[a][t] =
+                                        __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][ks], b[t], acc[a][t], 0, 0, 0);
+                        }
                     }
                 }
 #pragma unroll
@@ -208,21 +288,58 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     }
 
     // ---- epilogue
+    __syncthreads();  // ep[] visible even when the K loop ran zero chunks
+    const int cl_base = wco * (32 * TCO) + 4 * kk;  // channel index inside the block for (a=0, r=0)
+    const bool fast = (co_base + 32 * TCO <= p.Cout) && (p.cout_split == p.Cout);  // wave-uniform
+    if (fast) {
+        float* obase[TPX];
+#pragma unroll
+        for (int t = 0; t < TPX; ++t)
+            obase[t] = p.out1 + pn[t] * p.out1_ns + (long)(co_base + 4 * kk) * HW + ppix[t];
+#pragma unroll
+        for (int a = 0; a < TCO; ++a) {
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cidx = a * 32 + (r & 3) + 8 * (r >> 2);  // compile time
+                float e0 = 0.f, e1 = 1.f;
+                if (p.ep_mode != 0) {
+                    e0 = blockIdx.z == 0 ? ep[cl_base + cidx] : 0.f;  // the additive term enters once per output
+                    e1 = ep[BCO + cl_base + cidx];
+                }
+#pragma unroll
+                for (int t = 0; t < TPX; ++t) {
+                    float v = acc[a][t][r];
+                    if (p.ep_mode != 0) v = (v + e0) * e1;
+                    if (p.ep_mode == 1) {
+                        if (p.act == 1) v = v > 0.f ? v : 0.f;
+                        if (p.act == 2) v = v > 0.f ? v : 0.2f * v;
+                    }
+                    if (pvalid[t]) {
+                        float* dst = obase[t] + (long)cidx * HW;
+                        if (p.ksplit > 1) {
+                            atomicAdd(dst, v);
+                        } else {
+                            if (p.acc1) v += *dst;
+                            *dst = v;
+                        }
+                    }
+                }
+            }
+        }
+        return;
+    }
+    // general path: ragged Cout and/or output split over two tensors
 #pragma unroll
     for (int a = 0; a < TCO; ++a) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-            const int co = co_base + a * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+            const int cidx = a * 32 + (r & 3) + 8 * (r >> 2);
+            const int co = co_base + cidx + 4 * kk;
             if (co >= p.Cout) continue;
             float e0 = 0.f, e1 = 1.f;
-            if (p.ep_mode == 1) {
-                e0 = p.p0[co];
-                e1 = expf(p.p1[co]);
-            } else if (p.ep_mode == 2) {
-                e0 = p.p0[co];
-                e1 = expf(3.f * p.p1[co]);
-            } else if (p.ep_mode == 3) {
-                e0 = p.p0[co];
+            if (p.ep_mode != 0) {
+                e0 = blockIdx.z == 0 ? ep[cl_base + cidx] : 0.f;
+                e1 = ep[BCO + cl_base + cidx];
             }
             const bool first = co < p.cout_split;
             float* obase = first ? p.out1 : p.out2;
@@ -239,8 +356,12 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
                     if (p.act == 2) v = v > 0.f ? v : 0.2f * v;
                 }
                 float* dst = obase + pn[t] * ons + (long)oc * HW + ppix[t];
-                if (accm) v += *dst;
-                *dst = v;
+                if (p.ksplit > 1) {
+                    atomicAdd(dst, v);
+                } else {
+                    if (accm) v += *dst;
+                    *dst = v;
+                }
             }
         }
     }
@@ -266,10 +387,35 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
     p.n_wtiles = ceil_div(p.W, p.TWp);
     p.n_htiles = ceil_div(p.H, p.TH);
     p.n_ftiles = ceil_div(p.N, p.TF);
-    size_t lds = (size_t)KC * p.TF * (p.TH + 2 * PAD) * (p.TWp + 2 * PAD) * 4;
+    const int IMG = p.TF * (p.TH + 2 * PAD) * (p.TWp + 2 * PAD);
+    constexpr int NPOS = (KS == 1) ? 1 : (BPX >= 256 ? 4 : 2);
+    constexpr int P2 = (KS == 1 && BPX == 128) ? 128 : 256;
+    if (IMG > P2 * NPOS) {
+        rfn_set_error("conv2d: map %dx%d needs an LDS image of %d slots (> %d supported)", p.H, p.W, IMG, P2 * NPOS);
+        return -7;
+    }
+    size_t lds = ((size_t)KC * IMG + 2 * BCO) * 4;
     auto kern = conv_mfma_kernel<KS, WCO, WPX, TCO, TPX, KC>;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(p.n_wtiles * p.n_htiles * p.n_ftiles, ceil_div(p.Cout, BCO));
+    // Split K over gridDim.z when the (pixel, cout) grid alone cannot fill 256 CUs (ConvLSTM: 128 pixels x 800
+    // couts x K = 6408).  Needs a linear epilogue, dense zero-initialisable outputs and no accumulate flag.
+    p.ksplit = 1;
+    const int wgs = grid.x * grid.y;
+    const int nchunks = (p.Cin8 * 8 + KC - 1) / KC;
+    const int HW = p.H * p.W;
+    const bool dense = p.out1_ns == (long)p.cout_split * HW &&
+                       (p.cout_split == p.Cout || p.out2_ns == (long)(p.Cout - p.cout_split) * HW);
+    if (wgs < 128 && nchunks >= 8 && p.ep_mode != 1 && !p.acc1 && !p.acc2 && dense) {
+        int ks_ = 512 / wgs;
+        if (ks_ > nchunks / 2) ks_ = nchunks / 2;
+        if (ks_ > 1) {
+            p.ksplit = ks_;
+            (void)hipMemsetAsync(p.out1, 0, (size_t)p.N * p.cout_split * HW * 4, s);
+            if (p.cout_split != p.Cout) (void)hipMemsetAsync(p.out2, 0, (size_t)p.N * (p.Cout - p.cout_split) * HW * 4, s);
+        }
+    }
+    grid.z = p.ksplit;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
     return 0;
 }
@@ -294,21 +440,29 @@ extern "C" int rfn_conv2d_fwd_f32(const float* in1, long in1_ns, int C1, const f
     packed_dims(Cout, C1 + C2, &p.CoutP, &p.Cin8);
     p.ep_mode = ep_mode; p.act = act; p.p0 = p0; p.p1 = p1;
     hipStream_t s = (hipStream_t)stream;
+    int rc;
+    // few pixels in total (deep flow levels, ConvLSTM): 32-pixel tiles so that enough workgroups exist
+    const bool few_px = Cout > 64 && (long)N * H * W * ((Cout + 127) / 128) < 256L * 128;
     if (ks == 3) {
         if (Cout <= 32)
-            launch_conv<3, 1, 4, 1, 2, 8>(p, s);
+            rc = launch_conv<3, 1, 4, 1, 2, 8>(p, s);
         else if (Cout <= 64)
-            launch_conv<3, 1, 4, 2, 1, 8>(p, s);
+            rc = launch_conv<3, 1, 4, 2, 1, 8>(p, s);
+        else if (few_px)
+            rc = launch_conv<3, 4, 1, 1, 1, 8>(p, s);
         else
-            launch_conv<3, 2, 2, 2, 2, 8>(p, s);
+            rc = launch_conv<3, 2, 2, 2, 2, 8>(p, s);
     } else {
         if (Cout <= 32)
-            launch_conv<1, 1, 4, 1, 2, 32>(p, s);
+            rc = launch_conv<1, 1, 4, 1, 2, 32>(p, s);
         else if (Cout <= 64)
-            launch_conv<1, 1, 4, 2, 1, 32>(p, s);
+            rc = launch_conv<1, 1, 4, 2, 1, 32>(p, s);
+        else if (few_px)
+            rc = launch_conv<1, 4, 1, 1, 1, 32>(p, s);
         else
-            launch_conv<1, 2, 2, 2, 2, 32>(p, s);
+            rc = launch_conv<1, 2, 2, 2, 2, 32>(p, s);
     }
+    if (rc) return rc;
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -328,6 +482,7 @@ struct WgradParams {
     int N, H, W;
     int TWp, TH, TF, tw_shift, th_shift;
     int n_wtiles, n_htiles, n_ftiles, n_pix_tiles;
+    int P2, P2_shift;
 };
 
 template <int KS, int WCO, int WCI, int TCO, int TCI, int BPX>
@@ -357,6 +512,26 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[a][b][t][r] = 0.f;
 
+    // ---- staging descriptors (tile independent part computed once; see conv_mfma_kernel)
+    constexpr int GGRP = 256 / BPX;                      // G: thread -> pixel slot q, channel phase
+    const int gq = tid & (BPX - 1);
+    const int gphase = __builtin_amdgcn_readfirstlane(tid / BPX);
+    const int gcol = gq & (p.TWp - 1), grow = (gq >> p.tw_shift) & (p.TH - 1), gf = gq >> (p.tw_shift + p.th_shift);
+    constexpr int XNPOS = (KS == 1) ? 1 : 2;             // X: image slot(s) r = slot + P2*j, channel phase
+    const int xslot = tid & (p.P2 - 1), xgroups = 256 >> p.P2_shift;
+    const int xphase = __builtin_amdgcn_readfirstlane(tid >> p.P2_shift);
+    int xf[XNPOS], xyy[XNPOS], xxx[XNPOS];
+    bool xin[XNPOS];
+#pragma unroll
+    for (int j = 0; j < XNPOS; ++j) {
+        const int r = xslot + p.P2 * j;
+        xin[j] = r < IMG;
+        xf[j] = r / FRM;
+        const int rr = r - xf[j] * FRM;
+        xyy[j] = rr / RW;
+        xxx[j] = rr - xyy[j] * RW;
+    }
+
     for (int ptile = blockIdx.x; ptile < p.n_pix_tiles; ptile += gridDim.x) {
         int pt = ptile;
         const int wt = pt % p.n_wtiles;
@@ -365,30 +540,54 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
         const int ft = pt / p.n_htiles;
         const int x0 = wt * p.TWp, y0 = ht * p.TH, f0 = ft * p.TF;
         __syncthreads();
-        for (int idx = tid; idx < BCO * BPX; idx += 256) {
-            int cl = idx / BPX, q = idx - cl * BPX;
-            int col = q & (p.TWp - 1), row = (q >> p.tw_shift) & (p.TH - 1), f = q >> (p.tw_shift + p.th_shift);
-            int co = co0 + cl, n = f0 + f, gy = y0 + row, gx = x0 + col;
-            float v = 0.f;
-            if (co < p.Cout && n < p.N && gy < p.H && gx < p.W) v = p.g[n * p.g_ns + (long)co * HW + gy * p.W + gx];
-            Gs[cl * GSTR + q] = v;
-        }
-        for (int idx = tid; idx < BCI * IMG; idx += 256) {
-            int cl = idx / IMG, r = idx - cl * IMG;
-            int f = r / FRM, rr = r - f * FRM, yy = rr / RW, xx = rr - yy * RW;
-            int gy = y0 + yy - PAD, gx = x0 + xx - PAD, n = f0 + f, ch = ci0 + cl;
-            float v = 0.f;
-            if (ch < Cin && n < p.N && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W) {
-                if (ch < p.C1)
-                    v = p.in1[n * p.in1_ns + (long)ch * HW + gy * p.W + gx];
-                else
-                    v = p.in2[n * p.in2_ns + (long)(ch - p.C1) * HW + gy * p.W + gx];
+        {   // G tile [BCO][BPX]: batches of 8 unconditional loads (invalid -> element 0, zeroed afterwards)
+            const bool ok = (f0 + gf < p.N) && (y0 + grow < p.H) && (x0 + gcol < p.W);
+            const float* gsrc = p.g + (long)f0 * p.g_ns + (ok ? (long)gf * p.g_ns + (y0 + grow) * p.W + x0 + gcol : 0);
+            for (int cl0 = gphase; cl0 < BCO; cl0 += GGRP * 8) {
+                float v[8];
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int co = co0 + cl0 + u * GGRP;
+                    v[u] = gsrc[(long)(co < p.Cout ? co : 0) * HW];
+                }
+#pragma unroll
+                for (int u = 0; u < 8; ++u) {
+                    const int cl = cl0 + u * GGRP;
+                    if (cl < BCO) Gs[cl * GSTR + gq] = (ok && co0 + cl < p.Cout) ? v[u] : 0.f;
+                }
             }
-            Xs[cl * XSTR + r] = v;
+        }
+        {   // X tile [BCI][IMG] with halo, same batching
+            const float* in1b = p.in1 + (long)f0 * p.in1_ns;
+            const float* in2b = p.in2 ? p.in2 + (long)f0 * p.in2_ns : p.in1;
+#pragma unroll
+            for (int j = 0; j < XNPOS; ++j) {
+                if (!xin[j]) continue;
+                const int gy = y0 + xyy[j] - PAD, gx = x0 + xxx[j] - PAD;
+                const bool ok = (f0 + xf[j] < p.N) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+                const int off1 = ok ? (int)(xf[j] * p.in1_ns) + gy * p.W + gx : 0;
+                const int off2 = ok ? (int)(xf[j] * p.in2_ns) + gy * p.W + gx : 0;
+                float* xdst = Xs + xslot + p.P2 * j;
+                for (int cl0 = xphase; cl0 < BCI; cl0 += xgroups * 8) {
+                    float v[8];
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int ch = ci0 + cl0 + u * xgroups;
+                        const int chc = ch < Cin ? ch : 0;
+                        v[u] = chc < p.C1 ? in1b[(long)chc * HW + off1] : in2b[(long)(chc - p.C1) * HW + off2];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 8; ++u) {
+                        const int cl = cl0 + u * xgroups;
+                        if (cl < BCI) xdst[cl * XSTR] = (ok && ci0 + cl < Cin) ? v[u] : 0.f;
+                    }
+                }
+            }
         }
         __syncthreads();
         const float* ga = Gs + (wco * TCO * 32 + l31) * GSTR;
         const float* xb = Xs + (wci * TCI * 32 + l31) * XSTR;
+#pragma unroll 4
         for (int k2 = 0; k2 < BPX / 2; ++k2) {
             const int q = 2 * k2 + kk;
             const int col = q & (p.TWp - 1), row = (q >> p.tw_shift) & (p.TH - 1), f = q >> (p.tw_shift + p.th_shift);
@@ -437,6 +636,8 @@ static void launch_wgrad_bpx(WgradParams& p, hipStream_t s) {
     p.n_ftiles = ceil_div(p.N, p.TF);
     p.n_pix_tiles = p.n_wtiles * p.n_htiles * p.n_ftiles;
     int IMG = p.TF * (p.TH + 2 * PAD) * (p.TWp + 2 * PAD);
+    p.P2 = next_pow2(IMG) < 256 ? next_pow2(IMG) : 256;
+    p.P2_shift = ilog2(p.P2);
     size_t lds = ((size_t)BCO * (BPX + 1) + (size_t)BCI * (IMG | 1)) * 4;
     int tiles = ceil_div(p.Cout, BCO) * ceil_div(p.C1 + p.C2, BCI);
     int S = 1024 / tiles;

@@ -200,61 +200,89 @@ extern "C" int rfn_invconv_actnorm_rev_f32(const float* zin, long z_ns, const fl
     return 0;
 }
 
-// backward.  LDS: Y[C][PBS] and G[C][PBS] with PBS = PB+1 (odd stride: the gW phase reads rows with a stride).
+// backward.  LDS: Y[C][PBS] and G[C][PBS] with PBS = PB+1 (odd stride: the gW phase reads rows with a stride), plus
+// block-level accumulators Wacc[C*C], Bacc[C], Lacc[C].  A block sweeps many pixel tiles (grid-stride) and issues its
+// global float atomics ONCE at the end: a few hundred blocks x (C*C + 2C) atomics instead of one set per 256 pixels —
+// same-address atomics serialise at the memory side (MI355X_MICROARCH.md "Global float atomics": 14x slower).
 __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
     const float* __restrict__ x, long x_ns, const float* __restrict__ bias, const float* __restrict__ logs,
     const float* __restrict__ Wm, const float* __restrict__ gz, long gz_ns, float* __restrict__ gx, long gx_ns,
-    float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ glogs, int N, int C, int HW, int PB) {
+    float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ glogs, int N, int C, int HW, int PB,
+    int ntiles) {
     extern __shared__ float lds[];
     const int PBS = PB + 1;
-    float* Y = lds;            // [C][PBS]  y, later gy*y
-    float* G = lds + C * PBS;  // [C][PBS]  gz, later gy*exp(logs)
+    float* Y = lds;                   // [C][PBS]
+    float* G = lds + C * PBS;         // [C][PBS]
+    float* Wacc = lds + 2 * C * PBS;  // [C*C]
+    float* Bacc = Wacc + C * C;       // [C]
+    float* Lacc = Bacc + C;           // [C]
     const int t = threadIdx.x;
-    const long q = (long)blockIdx.x * PB + t;
-    const bool valid = t < PB && q < (long)N * HW;
-    int n = 0, p = 0;
-    if (valid) {
-        n = (int)(q / HW);
-        p = (int)(q % HW);
-    }
-    if (t < PB) {
-        for (int c = 0; c < C; ++c) {
-            float yv = 0.f, gv = 0.f;
-            if (valid) {
-                yv = (x[n * x_ns + (long)c * HW + p] + bias[c]) * expf(logs[c]);
-                gv = gz[n * gz_ns + (long)c * HW + p];
+    const int E = C * C;
+    for (int e = t; e < E + 2 * C; e += 256) Wacc[e] = 0.f;
+    const long total = (long)N * HW;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+        const long q = (long)tile * PB + t;
+        const bool valid = t < PB && q < total;
+        int n = 0, p = 0;
+        if (valid) {
+            n = (int)(q / HW);
+            p = (int)(q % HW);
+        }
+        __syncthreads();  // previous tile fully consumed (also orders the accumulator zeroing)
+        if (t < PB) {
+            for (int c = 0; c < C; ++c) {
+                float yv = 0.f, gv = 0.f;
+                if (valid) {
+                    yv = (x[n * x_ns + (long)c * HW + p] + bias[c]) * expf(logs[c]);
+                    gv = gz[n * gz_ns + (long)c * HW + p];
+                }
+                Y[c * PBS + t] = yv;
+                G[c * PBS + t] = gv;
             }
-            Y[c * PBS + t] = yv;
-            G[c * PBS + t] = gv;
+        }
+        __syncthreads();
+        // gW[i][j] += Σ_p gz_i(p) y_j(p): small C -> 256/(C*C) threads per entry split the pixels (LDS atomic
+        // combine); large C -> every thread owns entries e, e+256, ... (plain LDS read-modify-write, single owner)
+        if (E <= 256) {
+            const int e = t % E, grp = t / E, G_ = 256 / E;
+            if (grp < G_) {
+                const float* gi = G + (e / C) * PBS;
+                const float* yj = Y + (e % C) * PBS;
+                float a = 0.f;
+                for (int pp = grp; pp < PB; pp += G_) a = fmaf(gi[pp], yj[pp], a);
+                atomicAdd(&Wacc[e], a);
+            }
+        } else {
+            for (int e = t; e < E; e += 256) {
+                const float* gi = G + (e / C) * PBS;
+                const float* yj = Y + (e % C) * PBS;
+                float a = 0.f;
+                for (int pp = 0; pp < PB; ++pp) a = fmaf(gi[pp], yj[pp], a);
+                Wacc[e] += a;
+            }
+        }
+        // gy_j = Σ_i W[i][j] gz_i ; gx_j = gy_j * exp(logs_j) ; gbias_j += Σ gx_j ; glogs_j += Σ gy_j y_j.
+        // PB is a multiple of 64: whole waves are in or out, so wave_sum sees all 64 lanes; tail pixels are zeros.
+        if (t < PB) {
+            for (int j = 0; j < C; ++j) {
+                float a = 0.f;
+                for (int i = 0; i < C; ++i) a = fmaf(Wm[(long)i * C + j], G[i * PBS + t], a);
+                const float gxv = a * expf(logs[j]);
+                if (valid) gx[n * gx_ns + (long)j * HW + p] = gxv;
+                const float s1 = wave_sum(gxv);
+                const float s2 = wave_sum(a * Y[j * PBS + t]);
+                if ((t & 63) == 0) {
+                    atomicAdd(&Bacc[j], s1);
+                    atomicAdd(&Lacc[j], s2);
+                }
+            }
         }
     }
     __syncthreads();
-    // gW[i][j] += Σ_p gz_i(p) y_j(p)
-    for (int e = t; e < C * C; e += 256) {
-        int i = e / C, j = e % C;
-        const float* gi = G + i * PBS;
-        const float* yj = Y + j * PBS;
-        float a = 0.f;
-        for (int pp = 0; pp < PB; ++pp) a = fmaf(gi[pp], yj[pp], a);
-        atomicAdd(&gW[e], a);
-    }
-    __syncthreads();
-    // gy_j = Σ_i W[i][j] gz_i ; gx_j = gy_j * exp(logs_j) ; gbias_j += Σ gx_j ; glogs_j += Σ gy_j y_j.
-    // PB is a multiple of 64, so whole waves are in or out of this branch and wave_sum sees all 64 lanes;
-    // pixels past the end were staged as zeros and contribute nothing.
-    if (t < PB) {
-        for (int j = 0; j < C; ++j) {
-            float a = 0.f;
-            for (int i = 0; i < C; ++i) a = fmaf(Wm[(long)i * C + j], G[i * PBS + t], a);
-            float gxv = a * expf(logs[j]);
-            if (valid) gx[n * gx_ns + (long)j * HW + p] = gxv;
-            float s1 = wave_sum(gxv);
-            float s2 = wave_sum(a * Y[j * PBS + t]);
-            if ((t & 63) == 0) {
-                atomicAdd(&gbias[j], s1);
-                atomicAdd(&glogs[j], s2);
-            }
-        }
+    for (int e = t; e < E; e += 256) atomicAdd(&gW[e], Wacc[e]);
+    for (int c = t; c < C; c += 256) {
+        atomicAdd(&gbias[c], Bacc[c]);
+        atomicAdd(&glogs[c], Lacc[c]);
     }
 }
 
@@ -265,19 +293,21 @@ extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const floa
     RFN_CHECK_ARG(x && bias && logs && Wm && gz && gx && gW && gbias && glogs && N >= 0 && C > 0 && HW > 0, -1);
     if (N == 0) return 0;
     int PB = 256;
-    while ((long)2 * C * (PB + 1) * 4 > 65536 && PB > 64) PB >>= 1;
-    size_t lds = (size_t)2 * C * (PB + 1) * 4;
+    const size_t extra = ((size_t)C * C + 2 * C) * 4;
+    while ((size_t)2 * C * (PB + 1) * 4 + extra > 65536 && PB > 64) PB >>= 1;
+    size_t lds = (size_t)2 * C * (PB + 1) * 4 + extra;
     if (lds > 160 * 1024) {
         rfn_set_error("actnorm_invconv_bwd: C=%d too large", C);
         return -3;
     }
     if (lds > 65536)
         (void)hipFuncSetAttribute((const void*)actnorm_invconv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                            (int)lds);
+                                  (int)lds);
     long tot = (long)N * HW;
-    int grid = (int)((tot + PB - 1) / PB);
+    int ntiles = (int)((tot + PB - 1) / PB);
+    int grid = ntiles < 512 ? ntiles : 512;
     hipLaunchKernelGGL(actnorm_invconv_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, x_ns, bias, logs,
-                       Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB);
+                       Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB, ntiles);
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -354,20 +384,15 @@ extern "C" int rfn_affine_coupling_f32(float* z, long z_ns, const float* o, long
     return 0;
 }
 
-// backward: grid (N); per-channel parameter grads reduced per block through LDS then atomics.
+// backward: a block owns frames n = blockIdx.x, +gridDim.x, ...; each wave walks channels j = wave, wave+4, ... and for
+// a channel sweeps the block's frames, so the per-channel parameter sums stay in registers and reach global memory as
+// one atomic pair per (block, channel).
 __global__ __launch_bounds__(256) void affine_coupling_bwd_kernel(
     const float* __restrict__ zout, long zout_ns, const float* __restrict__ o, long o_ns,
     const float* __restrict__ gout, long gout_ns, const float* __restrict__ glogdet, const float* __restrict__ scale,
     const float* __restrict__ scale_shift, float* __restrict__ gz, long gz_ns, float* __restrict__ go, long go_ns,
-    float* __restrict__ gscale, float* __restrict__ gscale_shift, int clamp_type, int C, int HW) {
-    const int n = blockIdx.x, Ch = C >> 1;
-    const float* z2o = zout + n * zout_ns + (long)Ch * HW;
-    const float* g2 = gout + n * gout_ns + (long)Ch * HW;
-    const float* on = o + n * o_ns;
-    float* gz2 = gz + n * gz_ns + (long)Ch * HW;
-    float* gon = go + n * go_ns;
-    const float gld = glogdet ? glogdet[n] : 0.f;
-    // channel-major sweep so per-channel sums can be wave-reduced: each wave takes channels j = wave, wave+4, ...
+    float* __restrict__ gscale, float* __restrict__ gscale_shift, int clamp_type, int N, int C, int HW) {
+    const int Ch = C >> 1;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     for (int j = wave; j < Ch; j += 4) {
         float sc = 0.f, sh = 0.f;
@@ -376,20 +401,27 @@ __global__ __launch_bounds__(256) void affine_coupling_bwd_kernel(
             sh = scale_shift[j];
         }
         float a_sc = 0.f, a_sh = 0.f;
-        for (int p = lane; p < HW; p += 64) {
-            float s = on[(long)(2 * j + 1) * HW + p];
-            float ls = clamp_ls(s, clamp_type, sc, sh);
-            float e = expf(ls);
-            float g = g2[(long)j * HW + p];
-            float zo = z2o[(long)j * HW + p];
-            float gls = g * zo + gld;
-            float gzv = g * e;
-            gz2[(long)j * HW + p] = gzv;
-            gon[(long)(2 * j) * HW + p] = gzv;  // d/dshift
-            gon[(long)(2 * j + 1) * HW + p] = gls * clamp_ls_grad(s, clamp_type, sc);
-            if (clamp_type == 0) {
-                a_sc += gls * tanhf(s);
-                a_sh += gls;
+        for (int n = blockIdx.x; n < N; n += gridDim.x) {
+            const float* z2o = zout + n * zout_ns + (long)(Ch + j) * HW;
+            const float* g2 = gout + n * gout_ns + (long)(Ch + j) * HW;
+            const float* on = o + n * o_ns + (long)(2 * j) * HW;
+            float* gz2 = gz + n * gz_ns + (long)(Ch + j) * HW;
+            float* gon = go + n * go_ns + (long)(2 * j) * HW;
+            const float gld = glogdet ? glogdet[n] : 0.f;
+            for (int p = lane; p < HW; p += 64) {
+                const float s = on[HW + p];
+                const float ls = clamp_ls(s, clamp_type, sc, sh);
+                const float e = expf(ls);
+                const float g = g2[p];
+                const float gls = g * z2o[p] + gld;
+                const float gzv = g * e;
+                gz2[p] = gzv;
+                gon[p] = gzv;  // d/dshift
+                gon[HW + p] = gls * clamp_ls_grad(s, clamp_type, sc);
+                if (clamp_type == 0) {
+                    a_sc += gls * tanhf(s);
+                    a_sh += gls;
+                }
             }
         }
         if (clamp_type == 0) {
@@ -410,9 +442,9 @@ extern "C" int rfn_affine_coupling_bwd_f32(const float* zout, long zout_ns, cons
     RFN_CHECK_ARG(zout && o && gout && gz && go && N >= 0 && C > 0 && (C % 2 == 0) && HW > 0, -1);
     RFN_CHECK_ARG(clamp_type != 0 || (scale && scale_shift && gscale && gscale_shift), -2);
     if (N == 0) return 0;
-    hipLaunchKernelGGL(affine_coupling_bwd_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, zout, zout_ns, o, o_ns,
-                       gout, gout_ns, glogdet, scale, scale_shift, gz, gz_ns, go, go_ns, gscale, gscale_shift, clamp_type,
-                       C, HW);
+    hipLaunchKernelGGL(affine_coupling_bwd_kernel, dim3(N < 304 ? N : 304), dim3(256), 0, (hipStream_t)stream, zout,
+                       zout_ns, o, o_ns, gout, gout_ns, glogdet, scale, scale_shift, gz, gz_ns, go, go_ns, gscale,
+                       gscale_shift, clamp_type, N, C, HW);
     RFN_LAUNCH_CHECK();
     return 0;
 }

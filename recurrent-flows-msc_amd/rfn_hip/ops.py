@@ -106,13 +106,16 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
     L.call("rfn_conv2d_fwd_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(wpk), o1p, _l(o1ns), o2p,
            _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W), _i(ks),
            _i(ep_mode), L.dev(p0), L.dev(p1), _i(act),
-           meta=("conv", conv_kernel_name(Cout, ks), 2.0 * N * H * W * (C1 + C2) * Cout * ks * ks))
+           meta=("conv", conv_kernel_name(Cout, ks, N * H * W), 2.0 * N * H * W * (C1 + C2) * Cout * ks * ks,
+                 "N%d %d+%d->%d %dx%d k%d ep%d%s" % (N, C1, C2, Cout, H, W, ks, ep_mode,
+                                                  "" if cout_split == Cout else " split")))
     return out1
 
 
-def conv_kernel_name(Cout, ks):
+def conv_kernel_name(Cout, ks, npix=1 << 30):
     """the template instantiation rfn_conv2d_fwd_f32 dispatches to (mirrors csrc/conv.hip) — for profiling labels"""
-    cfg = "1,4,1,2" if Cout <= 32 else ("1,4,2,1" if Cout <= 64 else "2,2,2,2")
+    few = Cout > 64 and npix * ((Cout + 127) // 128) < 256 * 128
+    cfg = "1,4,1,2" if Cout <= 32 else ("1,4,2,1" if Cout <= 64 else ("4,1,1,1" if few else "2,2,2,2"))
     return "conv_mfma_kernel<%d,%s,%d>" % (ks, cfg, 8 if ks == 3 else 32)
 
 
@@ -135,7 +138,8 @@ def conv2d_wgrad(in1, in2, g, Cout, ks):
     gwt = torch.zeros((ks * ks, Cout, Cin), device=in1.device, dtype=torch.float32)
     L.call("rfn_conv2d_wgrad_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), gp, _l(gns), _i(Cout), L.dev(gwt),
            _i(N), _i(H), _i(W), _i(ks),
-           meta=("wgrad", wgrad_kernel_name(Cout, Cin, ks, H * W), 2.0 * N * H * W * Cin * Cout * ks * ks))
+           meta=("wgrad", wgrad_kernel_name(Cout, Cin, ks, H * W), 2.0 * N * H * W * Cin * Cout * ks * ks,
+                 "N%d %d->%d %dx%d k%d" % (N, Cin, Cout, H, W, ks)))
     gw = torch.empty((Cout, Cin, ks, ks), device=in1.device, dtype=torch.float32)
     L.call("rfn_wgrad_finish_f32", L.dev(gwt), L.dev(gw), _i(Cout), _i(Cin), _i(ks), _i(0))
     return gw

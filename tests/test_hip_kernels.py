@@ -90,6 +90,8 @@ CONV_CASES = [
     (1, 3, 0, 130, 8, 8, 3),     # Cout > 128 (two cout blocks), Cin < 8
     (2, 9, 0, 20, 64, 64, 3),    # W = 64 (two column tiles)
     (2, 40, 0, 33, 3, 5, 1),     # 3x5 map
+    (32, 512, 200, 800, 2, 2, 3),  # ConvLSTM conv: few pixels, huge K -> 32-pixel tiles + split-K (atomic combine)
+    (6, 100, 0, 200, 4, 4, 1),   # few-pixel 1x1, split-K
 ]
 
 
