@@ -12,6 +12,7 @@
 // A fragments of four consecutive k-steps; they stream straight from L2 into registers, prefetched one iteration ahead.
 #include "common.h"
 #include "../../include/rfn_hip.h"
+#include <stdlib.h>
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -35,6 +36,7 @@ struct ConvParams {
     int n_wtiles, n_htiles, n_ftiles;
     int P2, P2_shift;  // (unused by the forward kernel; kept for layout compatibility)
     int ksplit;        // gridDim.z: the K (input channel chunk) range is split over z, partial sums meet by atomicAdd
+    int w_lds_off;     // float offset of the weight tile inside dynamic LDS (16-byte aligned)
 };
 
 // packed weight index: (((g8*T + tap)*2 + kk)*CoutP + co)*4 + ks   <->  cin = g8*8 + 2*ks + kk
@@ -69,7 +71,7 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, float* __restric
 // CoutP is padded to the cout block of the kernel configuration chosen for this Cout (see rfn_conv2d_fwd_f32), so
 // every A-fragment load of a launched block stays inside the packed buffer.
 static inline void packed_dims(int Cout_l, int Cin_l, int* CoutP, int* Cin8) {
-    *CoutP = Cout_l <= 32 ? 32 : (Cout_l <= 64 ? 64 : ((Cout_l + 127) / 128) * 128);
+    *CoutP = Cout_l <= 32 ? 32 : (Cout_l <= 64 ? 64 : ((Cout_l + 255) / 256) * 256);
     *Cin8 = (Cin_l + 7) / 8;
 }
 
@@ -150,7 +152,8 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     // take alternate channels (GROUPS = 2); every other case has IMG > 128 and uses all 256 threads as slots.
     constexpr int BPX = 32 * TPX * WPX;
     constexpr int NPOS = (KS == 1) ? 1 : (BPX >= 256 ? 4 : 2);
-    constexpr int GROUPS = (KS == 1 && BPX == 128) ? 2 : 1;
+    // (P2 >= 64 keeps `phase` wave-uniform)
+    constexpr int GROUPS = (KS == 1 && BPX < 256) ? (BPX >= 64 ? 256 / BPX : 4) : 1;
     constexpr int P2 = 256 / GROUPS;
     const int slot = tid & (P2 - 1);
     const int phase = __builtin_amdgcn_readfirstlane(tid / P2);  // wave-uniform: keeps channel math scalar
@@ -199,12 +202,37 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
         }
     };
 
+    // ---- weights of one K chunk also go through LDS.  (Loading A fragments straight from L2 inside the MFMA loop
+    // looked free, but vmcnt retires in order: every such load queued behind the HBM prefetch of the next activation
+    // chunk and stalled the wave for a full HBM round trip per chunk.)  The packed layout is linear per (iteration,
+    // k-parity): runs of BCO float4, copied verbatim -> Ws4[(it_local*2 + kk)*BCO + cout_local].
     const int total_it = p.Cin8 * T;
     const f32x4* wp4 = reinterpret_cast<const f32x4*>(p.wpk);
-    // A fragment of iteration `it` for cout tile a:  wp4[(it*2 + kk)*CoutP + co_base + a*32 + l31]
-    f32x4 a_cur[TCO], a_nxt[TCO];
+    constexpr int ITC = (KC / 8) * T;               // iterations (8-channel group x tap) per chunk
+    constexpr int WRUNS = ITC * 2;                  // runs of BCO float4 per chunk
+    constexpr int WPT = (WRUNS * BCO + 255) / 256;  // float4 per thread per chunk
+    f32x4* Ws4 = reinterpret_cast<f32x4*>(lds + p.w_lds_off);
+    const long wblk = (long)blockIdx.y * BCO;
+    f32x4 wstg[WPT];
+    auto wprefetch = [&](int chunk) {
+        const int it0 = chunk * ITC;
 #pragma unroll
-    for (int a = 0; a < TCO; ++a) a_cur[a] = wp4[((long)0 * 2 + kk) * p.CoutP + co_base + a * 32 + l31];
+        for (int j = 0; j < WPT; ++j) {
+            const int e = tid + 256 * j;
+            const int run = e / BCO, col = e % BCO;  // BCO is a power of two
+            const int itg = it0 + (run >> 1);
+            const bool ok = (WRUNS * BCO % 256 == 0 || e < WRUNS * BCO) && itg < total_it;
+            const f32x4 v = wp4[((long)(ok ? itg : 0) * 2 + (run & 1)) * p.CoutP + wblk + col];
+            wstg[j] = ok ? v : f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto wcommit = [&]() {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int e = tid + 256 * j;
+            if (WRUNS * BCO % 256 == 0 || e < WRUNS * BCO) Ws4[e] = wstg[j];
+        }
+    };
 
     // epilogue parameters of this block's BCO channels -> LDS (read after the K loop; its barriers order the write)
     float* ep = lds + KC * IMG;  // [2][BCO]
@@ -226,63 +254,43 @@ __global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
     const int cps = (nchunks_all + p.ksplit - 1) / p.ksplit;  // chunks per K split
     const int chunk0 = blockIdx.z * cps;
     const int nchunks = chunk0 + cps < nchunks_all ? chunk0 + cps : nchunks_all;
-    if (p.ksplit > 1) {
-#pragma unroll
-        for (int a = 0; a < TCO; ++a)
-            a_cur[a] = wp4[((long)(chunk0 * (KC / 8) * T) * 2 + kk) * p.CoutP + co_base + a * 32 + l31];
+    if (chunk0 < nchunks) {
+        prefetch(chunk0);
+        wprefetch(chunk0);
     }
-    if (chunk0 < nchunks) prefetch(chunk0);
+    const f32x4* wa = Ws4 + kk * BCO + wco * (32 * TCO) + l31;  // + it_local*2*BCO + a*32
     for (int chunk = chunk0; chunk < nchunks; ++chunk) {
         __syncthreads();  // every wave is done reading the previous chunk
         commit();
+        wcommit();
         __syncthreads();
-        if (chunk + 1 < nchunks) prefetch(chunk + 1);  // global loads stay in flight under the MFMAs below
+        if (chunk + 1 < nchunks) {  // global loads of the next chunk stay in flight under the MFMAs below
+            prefetch(chunk + 1);
+            wprefetch(chunk + 1);
+        }
 #pragma unroll
         for (int s8 = 0; s8 < KC / 8; ++s8) {
-            const int g8 = chunk * (KC / 8) + s8;
-            if (g8 >= p.Cin8) break;
-            int nks = (Cin - g8 * 8 + 1) >> 1;
-            nks = nks > 4 ? 4 : nks;
 #pragma unroll
             for (int tap = 0; tap < T; ++tap) {
-                const int it = g8 * T + tap;
-                if (it + 1 < total_it) {
+                const int itl = s8 * T + tap;
+                f32x4 af[TCO];
 #pragma unroll
-                    for (int a = 0; a < TCO; ++a)
-                        a_nxt[a] = wp4[((long)(it + 1) * 2 + kk) * p.CoutP + co_base + a * 32 + l31];
-                }
+                for (int a = 0; a < TCO; ++a) af[a] = wa[itl * 2 * BCO + a * 32];
                 const int tapoff = (tap / KS) * RW + (tap % KS);
                 const float* lbase = lds + (s8 * 8 + kk) * IMG + tapoff;
-                if (nks == 4) {  // full group: no per-k-step branches, LDS reads free to run ahead of the MFMAs
+                // four k-steps of the 8-channel group, branch free.  Ragged Cin tails and groups past Cin multiply
+                // zero weights by zero-filled LDS rows.
 #pragma unroll
-                    for (int ks = 0; ks < 4; ++ks) {
-                        float b[TPX];
+                for (int ks = 0; ks < 4; ++ks) {
+                    float b[TPX];
 #pragma unroll
-                        for (int t = 0; t < TPX; ++t) b[t] = lbase[2 * ks * IMG + lds_off[t]];
+                    for (int t = 0; t < TPX; ++t) b[t] = lbase[2 * ks * IMG + lds_off[t]];
 #pragma unroll
-                        for (int a = 0; a < TCO; ++a)
+                    for (int a = 0; a < TCO; ++a)
 #pragma unroll
-                            for (int t = 0; t < TPX; ++t)
-                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][ks], b[t], acc[a][t], 0, 0, 0);
-                    }
-                } else {         // ragged tail of Cin (at most once per tap)
-#pragma unroll
-                    for (int ks = 0; ks < 3; ++ks) {
-                        if (ks < nks) {
-                            float b[TPX];
-#pragma unroll
-                            for (int t = 0; t < TPX; ++t) b[t] = lbase[2 * ks * IMG + lds_off[t]];
-#pragma unroll
-                            for (int a = 0; a < TCO; ++a)
-#pragma unroll
-                                for (int t = 0; t < TPX; ++t)
-                                    acc[a][t] =
-                                        __builtin_amdgcn_mfma_f32_32x32x2f32(a_cur[a][ks], b[t], acc[a][t], 0, 0, 0);
-                        }
-                    }
+                        for (int t = 0; t < TPX; ++t)
+                            acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[a][ks], b[t], acc[a][t], 0, 0, 0);
                 }
-#pragma unroll
-                for (int a = 0; a < TCO; ++a) a_cur[a] = a_nxt[a];
             }
         }
     }
@@ -389,12 +397,13 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
     p.n_ftiles = ceil_div(p.N, p.TF);
     const int IMG = p.TF * (p.TH + 2 * PAD) * (p.TWp + 2 * PAD);
     constexpr int NPOS = (KS == 1) ? 1 : (BPX >= 256 ? 4 : 2);
-    constexpr int P2 = (KS == 1 && BPX == 128) ? 128 : 256;
+    constexpr int P2 = (KS == 1 && BPX < 256) ? (BPX >= 64 ? BPX : 64) : 256;
     if (IMG > P2 * NPOS) {
         rfn_set_error("conv2d: map %dx%d needs an LDS image of %d slots (> %d supported)", p.H, p.W, IMG, P2 * NPOS);
         return -7;
     }
-    size_t lds = ((size_t)KC * IMG + 2 * BCO) * 4;
+    p.w_lds_off = ((KC * IMG + 2 * BCO + 3) / 4) * 4;
+    size_t lds = ((size_t)p.w_lds_off + (size_t)(KC / 8) * KS * KS * 2 * BCO * 4) * 4;
     auto kern = conv_mfma_kernel<KS, WCO, WPX, TCO, TPX, KC>;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(p.n_wtiles * p.n_htiles * p.n_ftiles, ceil_div(p.Cout, BCO));
@@ -459,8 +468,18 @@ extern "C" int rfn_conv2d_fwd_f32(const float* in1, long in1_ns, int C1, const f
             rc = launch_conv<1, 1, 4, 2, 1, 32>(p, s);
         else if (few_px)
             rc = launch_conv<1, 4, 1, 1, 1, 32>(p, s);
-        else
-            rc = launch_conv<1, 2, 2, 2, 2, 32>(p, s);
+        else {
+            static int variant = getenv("RFN_CONV_VARIANT") ? atoi(getenv("RFN_CONV_VARIANT")) : 0;
+            switch (variant) {
+                case 1: rc = launch_conv<1, 2, 2, 2, 2, 64>(p, s); break;
+                case 2: rc = launch_conv<1, 2, 2, 2, 4, 32>(p, s); break;
+                case 3: rc = launch_conv<1, 4, 1, 2, 2, 32>(p, s); break;
+                case 4: rc = launch_conv<1, 2, 2, 4, 2, 32>(p, s); break;
+                case 5: rc = launch_conv<1, 2, 2, 2, 2, 16>(p, s); break;
+                case 6: rc = launch_conv<1, 2, 2, 2, 2, 32>(p, s); break;
+                default: rc = launch_conv<1, 4, 1, 2, 2, 32>(p, s);
+            }
+        }
     }
     if (rc) return rc;
     RFN_LAUNCH_CHECK();
@@ -543,15 +562,16 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
         {   // G tile [BCO][BPX]: batches of 8 unconditional loads (invalid -> element 0, zeroed afterwards)
             const bool ok = (f0 + gf < p.N) && (y0 + grow < p.H) && (x0 + gcol < p.W);
             const float* gsrc = p.g + (long)f0 * p.g_ns + (ok ? (long)gf * p.g_ns + (y0 + grow) * p.W + x0 + gcol : 0);
-            for (int cl0 = gphase; cl0 < BCO; cl0 += GGRP * 8) {
-                float v[8];
+            constexpr int GB = 32;  // loads in flight per thread per batch
+            for (int cl0 = gphase; cl0 < BCO; cl0 += GGRP * GB) {
+                float v[GB];
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < GB; ++u) {
                     const int co = co0 + cl0 + u * GGRP;
                     v[u] = gsrc[(long)(co < p.Cout ? co : 0) * HW];
                 }
 #pragma unroll
-                for (int u = 0; u < 8; ++u) {
+                for (int u = 0; u < GB; ++u) {
                     const int cl = cl0 + u * GGRP;
                     if (cl < BCO) Gs[cl * GSTR + gq] = (ok && co0 + cl < p.Cout) ? v[u] : 0.f;
                 }
@@ -568,16 +588,17 @@ __global__ __launch_bounds__(256) void wgrad_mfma_kernel(const WgradParams p) {
                 const int off1 = ok ? (int)(xf[j] * p.in1_ns) + gy * p.W + gx : 0;
                 const int off2 = ok ? (int)(xf[j] * p.in2_ns) + gy * p.W + gx : 0;
                 float* xdst = Xs + xslot + p.P2 * j;
-                for (int cl0 = xphase; cl0 < BCI; cl0 += xgroups * 8) {
-                    float v[8];
+                constexpr int XB = 32;
+                for (int cl0 = xphase; cl0 < BCI; cl0 += xgroups * XB) {
+                    float v[XB];
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < XB; ++u) {
                         const int ch = ci0 + cl0 + u * xgroups;
                         const int chc = ch < Cin ? ch : 0;
                         v[u] = chc < p.C1 ? in1b[(long)chc * HW + off1] : in2b[(long)(chc - p.C1) * HW + off2];
                     }
 #pragma unroll
-                    for (int u = 0; u < 8; ++u) {
+                    for (int u = 0; u < XB; ++u) {
                         const int cl = cl0 + u * xgroups;
                         if (cl < BCI) xdst[cl * XSTR] = (ok && ci0 + cl < Cin) ? v[u] : 0.f;
                     }

@@ -115,7 +115,8 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
 def conv_kernel_name(Cout, ks, npix=1 << 30):
     """the template instantiation rfn_conv2d_fwd_f32 dispatches to (mirrors csrc/conv.hip) — for profiling labels"""
     few = Cout > 64 and npix * ((Cout + 127) // 128) < 256 * 128
-    cfg = "1,4,1,2" if Cout <= 32 else ("1,4,2,1" if Cout <= 64 else ("4,1,1,1" if few else "2,2,2,2"))
+    cfg = "1,4,1,2" if Cout <= 32 else ("1,4,2,1" if Cout <= 64 else ("4,1,1,1" if few else
+                                                                     ("4,1,2,2" if ks == 1 else "2,2,2,2")))
     return "conv_mfma_kernel<%d,%s,%d>" % (ks, cfg, 8 if ks == 3 else 32)
 
 

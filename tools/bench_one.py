@@ -1,0 +1,20 @@
+#!/usr/bin/env python3
+"""Developer tool: run ONE conv shape repeatedly (for rocprofv3 --pmc).  args: kind cin cout S ks [N]"""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "recurrent-flows-msc_amd"))
+import torch
+from rfn_hip import ops as K
+kind, cin, cout, S, ks = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
+N = int(sys.argv[6]) if len(sys.argv) > 6 else 608
+x = torch.randn(N, cin, S, S, device="cuda")
+w = torch.randn(cout, cin, ks, ks, device="cuda") * 0.05
+g = torch.randn(N, cout, S, S, device="cuda")
+wp = K.pack_weight(w)
+out = torch.empty(N, cout, S, S, device="cuda")
+for _ in range(5):
+    if kind == "fwd":
+        K.conv2d_raw(x, None, wp, cout, ks, out1=out)
+    else:
+        K.conv2d_wgrad(x, None, g, cout, ks)
+torch.cuda.synchronize()
