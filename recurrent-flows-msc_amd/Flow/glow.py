@@ -44,7 +44,10 @@ class GlowStep(nn.Module):
             ld = torch.slogdet(self.invconv.weight)[1]
         return (ld + torch.sum(self.norm.logs)) * hw
 
-    def forward(self, x, condition, logdet, reverse):
+    def forward(self, x, condition, logdet, reverse, Wm=None, defer_logdet=None):
+        """`Wm` (optional): this step's C×C matrix when the caller built all matrices of a level in one batched
+        computation; `defer_logdet` (optional list): receives the data dependent log-det [N] instead of adding it (the
+        caller sums all steps at once and adds the parameter-only terms per level)."""
         if self.flow_norm == "batchnorm":  # non-default variant: unfused module chain
             if not reverse:
                 x, logdet = self.norm(x, logdet, reverse=False)
@@ -61,14 +64,17 @@ class GlowStep(nn.Module):
             if an.needs_init():  # data dependent init, first training call (glow_modules.py:22-36)
                 an.initialize(x)
                 an.mark_initialized()
-            Wm, _ = self.invconv.get_weight(x, reverse=False)
+            if Wm is None:
+                Wm, _ = self.invconv.get_weight(x, reverse=False)
             if aff.net[0].norm_type.needs_init() or aff.net[2].norm_type.needs_init():
                 with torch.no_grad():
                     z = K.actnorm_invconv_fwd(x.detach(), an.bias.detach().reshape(-1), an.logs.detach().reshape(-1),
                                               Wm.detach())
                     aff.maybe_init(z[:, : z.shape[1] // 2], condition)
             out, dl = K.GlowStepFn.apply(x, condition, Wm, an.bias, an.logs, *aff.nn_params(), act, clamp)
-            if logdet is not None:
+            if defer_logdet is not None:
+                defer_logdet.append(dl)
+            elif logdet is not None:
                 logdet = logdet + dl + self._param_logdet(x)
             return out, logdet
         if an.needs_init():
@@ -120,17 +126,59 @@ class ListGlow(nn.Module):
             )
 
     # ---- x -> z ------------------------------------------------------------------------------------------
+    def _level_steps(self):
+        """glow_frame grouped per level: [(squeeze, [GlowStep]*K, split|None)] (built once)."""
+        if getattr(self, "_levels", None) is None:
+            levels, cur = [], None
+            for m in self.glow_frame:
+                if isinstance(m, Squeeze2d):
+                    cur = [m, [], None]
+                    levels.append(cur)
+                elif isinstance(m, Split2d):
+                    cur[2] = m
+                else:
+                    cur[1].append(m)
+            self._levels = levels
+        return self._levels
+
+    @staticmethod
+    def _batched_invconv(steps, hw):
+        """All K matrices W = P·L·U of a level in ONE batched computation (glow_modules.py:188-205) plus the level's
+        InvConv part of the parameter-only log-det, Σ_k Σ log_s·H·W: a handful of launches per level, not per step."""
+        ics = [s.invconv for s in steps]
+        if not all(ic.LU_decomposed for ic in ics) or any(s.flow_norm == "batchnorm" for s in steps):
+            return None, None
+        lower = torch.stack([ic.lower for ic in ics])
+        upper = torch.stack([ic.upper for ic in ics])
+        log_s = torch.stack([ic.log_s for ic in ics])
+        sign_s = torch.stack([ic.sign_s for ic in ics])
+        p = torch.stack([ic.p for ic in ics])
+        l_mask, eye = ics[0].l_mask, ics[0].eye
+        L = lower * l_mask + eye
+        U = upper * l_mask.t() + torch.diag_embed(sign_s * torch.exp(log_s))
+        W = torch.matmul(p, torch.matmul(L, U))
+        return W, log_s.sum() * hw
+
     def f(self, x, condition, logdet):
-        """Flow/glow.py:105-117."""
-        z, l = x, 0
-        for step in self.glow_frame:
-            if isinstance(step, Squeeze2d):
-                z = step(z, undo_squeeze=False)
-            elif isinstance(step, Split2d):
-                z, logdet = step(z, condition[l], logdet=logdet, reverse=False)
-                l += 1
-            else:
-                z, logdet = step(z, condition[l], logdet=logdet, reverse=False)
+        """Flow/glow.py:105-117 (same order of operations; per-level batching of the tiny parameter algebra)."""
+        z = x
+        dls, const = [], 0
+        for l, (squeeze, steps, split) in enumerate(self._level_steps()):
+            z = squeeze(z, undo_squeeze=False)
+            W, c = self._batched_invconv(steps, z.shape[2] * z.shape[3])
+            for k, step in enumerate(steps):
+                if W is not None:
+                    z, _ = step(z, condition[l], logdet=logdet, reverse=False, Wm=W[k], defer_logdet=dls)
+                else:
+                    z, logdet = step(z, condition[l], logdet=logdet, reverse=False)
+            if W is not None:
+                # ActNorm logs are read AFTER the steps ran: the first training call initialises them in place
+                logs = torch.stack([s.norm.logs.reshape(-1) for s in steps])
+                const = const + c + logs.sum() * (z.shape[2] * z.shape[3])
+            if split is not None:
+                z, logdet = split(z, condition[l], logdet=logdet, reverse=False)
+        if logdet is not None and dls:
+            logdet = logdet + torch.stack(dls).sum(0) + const
         return z, logdet
 
     # ---- z -> x ------------------------------------------------------------------------------------------

@@ -138,12 +138,18 @@ class RFN(nn.Module):
             return draws.pop(0).to(dev) if draws is not None else torch.randn(ref.shape, device=dev)
 
         hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
-        feats = [self.extractor(x[:, i]) for i in range(T)]
+        # extractor on all T frames at once (step-major), BatchNorm statistics per timestep as in the reference
+        x_tm = x.transpose(0, 1).reshape(T * B, *x.shape[2:])
+        feats_tb = self.extractor.forward_steps(x_tm, T)
+        if self.single_feature:
+            feats = [feats_tb[i * B:(i + 1) * B] for i in range(T)]
+        else:
+            feats = [[f[i * B:(i + 1) * B] for f in feats_tb] for i in range(T)]
         store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
 
         kl_loss = 0
         st_mean, st_std, st_zx = [], [], []
-        conds_t, base_t, noise_t = [], [], []
+        base_t, noise_t = [], []
         for i in range(1, T):
             ht = store_ht[i - 1]
             if self.enable_smoothing:
@@ -159,7 +165,6 @@ class RFN(nn.Module):
             zxt = enc_mean + enc_std * eps_like(enc_mean)           # dist_enc.rsample()
             st_mean.append(enc_mean); st_std.append(enc_std); st_zx.append(zxprev)
             hz = torch.cat((ht, zxt), dim=1)
-            conds_t.append(self._flow_conditions(hz, feats[i - 1]))
             base_t.append(hz)
             if draws is not None:
                 noise_t.append(draws.pop(0).to(dev))
@@ -168,9 +173,19 @@ class RFN(nn.Module):
             zprev, zxprev = zt, zxt
 
         # ---- the decoder: all B*(T-1) frames in one call, t-major
-        xs = x[:, 1:].transpose(0, 1).reshape((T - 1) * B, *x.shape[2:])
-        conds = [torch.cat([c[l] for c in conds_t], dim=0) for l in range(self.L)]
+        xs = x_tm[B:]
         base = torch.cat(base_t, dim=0)
+        # upscaler for all T-1 steps at once; its skip maps are the extractor features of frames 0..T-2
+        n1 = (T - 1) * B
+        skips = None if self.single_feature else [f[:n1] for f in feats_tb]
+        if self.skip_connection_features:
+            conds = self.upscaler.forward_steps(base, T - 1, skip_list=skips)
+        else:
+            conds = self.upscaler.forward_steps(base, T - 1)
+        if self.skip_connection_flow == "with_skip":
+            conds = self.combineconditions(conds, skips)
+        elif self.skip_connection_flow == "only_skip":
+            conds = skips
         noise = torch.cat(noise_t, dim=0) if noise_t else None
         if self.training and self._flow_needs_init():
             with torch.no_grad():  # data dependent init on the t = 1 batch, as the reference's first call does

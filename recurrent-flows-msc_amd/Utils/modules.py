@@ -51,6 +51,45 @@ class NormLayer(nn.Module):
         return self.norm(x)
 
 
+def per_step_batchnorm(bn, x, steps):
+    """`bn` (nn.BatchNorm2d, training mode) applied to a step-major time-batched tensor [steps*B, C, H, W] with the
+    statistics of EACH step's B samples — what `steps` separate calls bn(x_t) compute (the reference runs its extractor
+    and upscaler once per timestep, RFN_new.py:126-128,191-194), including the running-statistics EMA applied in step
+    order.  One set of reductions / elementwise launches instead of `steps` of them."""
+    if not (bn.training or not bn.track_running_stats):
+        return bn(x)
+    SB, C, H, W = x.shape
+    B = SB // steps
+    xv = x.view(steps, B, C, H, W)
+    mean = xv.mean(dim=(1, 3, 4), keepdim=True)
+    var = xv.var(dim=(1, 3, 4), unbiased=False, keepdim=True)
+    y = (xv - mean) * torch.rsqrt(var + bn.eps)
+    if bn.affine:
+        y = y * bn.weight.view(1, 1, C, 1, 1) + bn.bias.view(1, 1, C, 1, 1)
+    if bn.track_running_stats and bn.training:
+        with torch.no_grad():
+            n = B * H * W
+            m = bn.momentum if bn.momentum is not None else 0.1
+            # r <- (1-m) r + m s_t for t = 0..steps-1  ==  (1-m)^S r + Σ_t m (1-m)^(S-1-t) s_t
+            coef = m * (1.0 - m) ** torch.arange(steps - 1, -1, -1, device=x.device, dtype=x.dtype)
+            decay = (1.0 - m) ** steps
+            bn.running_mean.mul_(decay).add_((coef.view(steps, 1) * mean.detach().view(steps, C)).sum(0))
+            unb = var.detach().view(steps, C) * (n / max(n - 1, 1))
+            bn.running_var.mul_(decay).add_((coef.view(steps, 1) * unb).sum(0))
+            bn.num_batches_tracked += steps
+    return y.view(SB, C, H, W)
+
+
+def run_time_batched(seq, x, steps):
+    """run an nn.Sequential on a step-major time-batched tensor, BatchNorm statistics per step."""
+    for m in seq:
+        if isinstance(m, NormLayer) and isinstance(m.norm, nn.BatchNorm2d):
+            x = per_step_batchnorm(m.norm, x, steps)
+        else:
+            x = m(x)
+    return x
+
+
 class Squeeze2dDecoder(nn.Module):
     """Utils/modules.py:122-138 — space-to-depth inside the extractor/upscaler (same index map as Flow.Squeeze2d)."""
 
@@ -131,6 +170,17 @@ class VGG_downscaler(nn.Module):
                 outputs = x
         return outputs
 
+    def forward_steps(self, x, steps):
+        """all `steps` per-timestep calls of forward() at once on a step-major [steps*B, C, H, W] tensor."""
+        outputs = []
+        for i in range(self.L):
+            x = run_time_batched(self.l_nets[i], x, steps)
+            if self.skip_con:
+                outputs.append(x)
+            else:
+                outputs = x
+        return outputs
+
 
 class VGG_upscaler(nn.Module):
     """Utils/modules.py:147-214 — L blocks; block l>0 begins with an up-sampling stage kept in `upscales_nets[l-1]`;
@@ -181,6 +231,20 @@ class VGG_upscaler(nn.Module):
                 x = self.l_nets[i](torch.cat((x, rev[i]), dim=1))
             else:
                 x = self.l_nets[i](x)
+            outputs.append(x)
+        outputs.reverse()
+        return outputs
+
+    def forward_steps(self, x, steps, skip_list=None):
+        """all `steps` per-timestep calls of forward() at once (step-major time-batched x and skip maps)."""
+        outputs = []
+        rev = list(reversed(skip_list)) if self.skips else None
+        for i in range(self.L):
+            if i > 0:
+                x = run_time_batched(self.upscales_nets[i - 1], x, steps)
+            if self.skips:
+                x = torch.cat((x, rev[i]), dim=1)
+            x = run_time_batched(self.l_nets[i], x, steps)
             outputs.append(x)
         outputs.reverse()
         return outputs

@@ -185,3 +185,28 @@ def test_data_parallel_reducer_world2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "rank %d ok" % r in o
+
+
+def test_per_step_batchnorm_equals_sequential_calls():
+    """time-batched BatchNorm with per-step statistics == one nn.BatchNorm2d call per step (outputs, grads, EMA)."""
+    from Utils.modules import per_step_batchnorm
+    g = torch.Generator().manual_seed(0)
+    S, B, C = 5, 3, 4
+    x = torch.randn(S * B, C, 6, 6, generator=g) * 2 + 1
+    bn_a, bn_b = torch.nn.BatchNorm2d(C), torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn_a.weight.uniform_(0.5, 1.5); bn_a.bias.uniform_(-1, 1)
+        bn_b.load_state_dict(bn_a.state_dict())
+    xa = x.clone().requires_grad_(True)
+    xb = x.clone().requires_grad_(True)
+    ya = torch.cat([bn_a(xa[t * B:(t + 1) * B]) for t in range(S)])
+    yb = per_step_batchnorm(bn_b, xb, S)
+    torch.testing.assert_close(yb, ya, rtol=1e-5, atol=1e-5)
+    w = torch.randn(ya.shape, generator=g)
+    (ya * w).sum().backward()
+    (yb * w).sum().backward()
+    torch.testing.assert_close(xb.grad, xa.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn_b.weight.grad, bn_a.weight.grad, rtol=1e-4, atol=1e-5)
+    torch.testing.assert_close(bn_b.running_mean, bn_a.running_mean, rtol=1e-5, atol=1e-6)
+    torch.testing.assert_close(bn_b.running_var, bn_a.running_var, rtol=1e-5, atol=1e-6)
+    assert int(bn_b.num_batches_tracked) == int(bn_a.num_batches_tracked) == S
