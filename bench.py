@@ -176,10 +176,13 @@ def main():
     rank = int(os.environ.get("RANK", 0))
     local = int(os.environ.get("LOCAL_RANK", 0))
     assert torch.cuda.is_available(), "bench.py needs a GPU (the HIP path has no fallback)"
+    if os.environ.get("RFN_SINGLE_GPU"):
+        local = 0
     torch.cuda.set_device(local)
     device = torch.device("cuda", local)
     if world > 1:
-        dist.init_process_group("nccl")
+        # RFN_DIST_BACKEND=gloo + RFN_SINGLE_GPU=1: rehearsal of the N>1 path on a one-GPU box (all ranks on cuda:0)
+        dist.init_process_group(os.environ.get("RFN_DIST_BACKEND", "nccl"))
     assert a.batch % world == 0, "global batch must divide over ranks"
     B_local = a.batch // world
 

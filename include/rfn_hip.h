@@ -86,6 +86,17 @@ int rfn_conv2d_wgrad_f32(const float* in1, long in1_ns, int C1, const float* in2
 /* gw[Cout][Cin][ks][ks] (torch layout) = (accumulate ? gw : 0) + transpose of gwt[ks*ks][Cout][Cin]. */
 int rfn_wgrad_finish_f32(const float* gwt, float* gw, int Cout, int Cin, int ks, int accumulate, rfn_stream_t stream);
 
+/* Tap-expanded form of a 3x3 convolution with very few output channels (Conv2dZeros at the shallow flow levels,
+ * glow_modules.py:106-121 with Cout = 4 / 8): the conv runs as a 1x1 rfn_conv2d_fwd_f32 to 9*C channels
+ * P[n][tap*C+co] (dense [N,9C,H,W]); rfn_tap_gather_f32 then forms
+ *   o[n][co][y][x] = (Σ_tap P[n][tap*C+co][y+dy-1][x+dx-1] + bias[co]) * exp(3*logs[co])   (bias/logs both NULL: plain sum).
+ * rfn_tap_scatter_f32 is the adjoint data movement used for the weight gradient:
+ *   Gs[n][tap*C+co][y][x] = g[n][co][y-dy+1][x-dx+1] (0 outside); a 1x1 rfn_conv2d_wgrad_f32 of Gs gives gW[co][ci][tap].
+ * All tensors dense NCHW. */
+int rfn_tap_gather_f32(const float* P, const float* bias, const float* logs, float* o, int N, int C, int H, int W,
+                       rfn_stream_t stream);
+int rfn_tap_scatter_f32(const float* g, float* Gs, int N, int C, int H, int W, rfn_stream_t stream);
+
 /* backward through  y = act((u + b[c]) * exp(l[c]))  (ep_mode 1) or  y = (u + b[c]) * exp(3 l[c])  (ep_mode 2),
  * given y (saved forward output) and gy:   gu (may alias gy) ;  gb[c] += ...;  gl[c] += ...  (accumulated). */
 int rfn_conv_epilogue_bwd_f32(const float* y, long y_ns, const float* gy, long gy_ns, float* gu, long gu_ns,

@@ -470,7 +470,7 @@ extern "C" int rfn_conv2d_fwd_f32(const float* in1, long in1_ns, int C1, const f
             rc = launch_conv<1, 4, 1, 1, 1, 32>(p, s);
         else {
             static int variant = getenv("RFN_CONV_VARIANT") ? atoi(getenv("RFN_CONV_VARIANT")) : 0;
-            switch (variant) {
+            switch (Cout <= 128 ? 6 : variant) {  // <= 128 couts: one 128-row block, not a half-empty 256-row one
                 case 1: rc = launch_conv<1, 2, 2, 2, 2, 64>(p, s); break;
                 case 2: rc = launch_conv<1, 2, 2, 2, 4, 32>(p, s); break;
                 case 3: rc = launch_conv<1, 4, 1, 2, 2, 32>(p, s); break;
@@ -704,6 +704,8 @@ extern "C" int rfn_conv2d_wgrad_f32(const float* in1, long in1_ns, int C1, const
             launch_wgrad<1, 4, 1, 2, 1>(p, s);   // 256 co x 32 ci
         else if (Cout <= 32)
             launch_wgrad<1, 1, 4, 1, 2>(p, s);   // 32 co x 256 ci
+        else if (Cout <= 64)
+            launch_wgrad_bpx<1, 1, 4, 2, 2, 64>(p, s);  // 64 co x 256 ci (tap-expanded conv3 at level 0: 36 rows)
         else
             launch_wgrad<1, 2, 2, 2, 2>(p, s);   // 128 x 128
     }

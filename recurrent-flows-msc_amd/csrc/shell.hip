@@ -627,6 +627,69 @@ extern "C" int rfn_conv_epilogue_bwd_f32(const float* y, long y_ns, const float*
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ tap gather / scatter
+// A 3x3 convolution with very few output channels (Conv2dZeros at the shallow flow levels: 256 -> 4 / 8) wastes a
+// 32-row MFMA tile.  It is computed instead as a 1x1 convolution to 9*C "tap-expanded" channels
+//   P[n][tap*C + co][p] = Σ_ci W[co][ci][tap] x[n][ci][p]
+// followed by this shift-and-add:  o[n][co][y][x] = (Σ_tap P[n][tap*C+co][y+dy-1][x+dx-1] + b[co]) * exp(3 l[co]).
+// tap_scatter is its adjoint data movement for the weight gradient:
+//   Gs[n][tap*C + co][y'][x'] = g[n][co][y'-dy+1][x'-dx+1]   (0 outside), so gW[co][ci][tap] = Σ Gs[tap*C+co] · x[ci].
+__global__ void tap_gather_kernel(const float* __restrict__ P, const float* __restrict__ b, const float* __restrict__ l,
+                                  float* __restrict__ o, int N, int C, int H, int W) {
+    const long HW = (long)H * W, total = (long)N * C * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        long r = idx / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int co = (int)(r % C);
+        const long n = r / C;
+        const float* Pn = P + n * 9 * C * HW;
+        float a = 0.f;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) a += Pn[((long)t * C + co) * HW + (long)yy * W + xx];
+        }
+        o[idx] = b ? (a + b[co]) * expf(3.f * l[co]) : a;
+    }
+}
+__global__ void tap_scatter_kernel(const float* __restrict__ g, float* __restrict__ Gs, int N, int C, int H, int W) {
+    const long HW = (long)H * W, total = (long)N * 9 * C * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        long r = idx / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int tc = (int)(r % (9 * C));
+        const long n = r / (9 * C);
+        const int t = tc / C, co = tc - t * C;
+        const int yy = y - (t / 3 - 1), xx = x - (t % 3 - 1);
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = g[(n * C + co) * HW + (long)yy * W + xx];
+        Gs[idx] = v;
+    }
+}
+extern "C" int rfn_tap_gather_f32(const float* P, const float* bias, const float* logs, float* o, int N, int C, int H,
+                                  int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(P && o && N >= 0 && C > 0 && H > 0 && W > 0 && ((bias && logs) || (!bias && !logs)), -1);
+    if (N == 0) return 0;
+    long tot = (long)N * C * H * W;
+    int grid = (int)((tot + 255) / 256 < 4096 ? (tot + 255) / 256 : 4096);
+    hipLaunchKernelGGL(tap_gather_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, P, bias, logs, o, N, C, H, W);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int rfn_tap_scatter_f32(const float* g, float* Gs, int N, int C, int H, int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(g && Gs && N >= 0 && C > 0 && H > 0 && W > 0, -1);
+    if (N == 0) return 0;
+    long tot = (long)N * 9 * C * H * W;
+    int grid = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    hipLaunchKernelGGL(tap_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, Gs, N, C, H, W);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ ConvLSTM gates
 __global__ void convlstm_gates_fwd_kernel(const float* __restrict__ cc, const float* __restrict__ c_prev, long c_ns,
                                           const float* __restrict__ Wci, const float* __restrict__ Wcf,

@@ -33,6 +33,8 @@ SIGNATURES = {
     "rfn_pack_conv_weight_f32": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_conv2d_wgrad_f32": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_wgrad_finish_f32": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_tap_gather_f32": [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_tap_scatter_f32": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_conv_epilogue_bwd_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i,
                                   _c_s],
     "rfn_affine_coupling_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],

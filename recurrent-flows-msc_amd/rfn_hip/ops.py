@@ -146,6 +146,33 @@ def conv2d_wgrad(in1, in2, g, Cout, ks):
     return gw
 
 
+TAP_MAX_COUT = 8  # 3x3 convs with at most this many outputs run tap-expanded (1x1 to 9*C channels + shift-add)
+
+
+def zeros_conv_fwd(x, w, b, logs):
+    """Conv2dZeros forward (glow_modules.py:119-121): (conv3x3(x) + b) * exp(3 logs).  Tiny Cout -> tap-expanded."""
+    C, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+    if ks != 3 or C > TAP_MAX_COUT:
+        return conv2d_raw(x, None, pack_weight(w), C, ks, 2, b, logs, 0)
+    N, _, H, W = x.shape
+    wt = w.detach().permute(2, 3, 0, 1).reshape(9 * C, Cin, 1, 1).contiguous()  # [tap*C + co][ci]
+    P = conv2d_raw(x, None, pack_weight(wt), 9 * C, 1)
+    o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+    L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b), L.dev(logs), L.dev(o), _i(N), _i(C), _i(H), _i(W))
+    return o
+
+
+def zeros_conv_wgrad(x, g_pre, C, ks):
+    """weight gradient of the conv inside Conv2dZeros given g_pre = grad wrt (conv + b); same switch as the forward."""
+    if ks != 3 or C > TAP_MAX_COUT:
+        return conv2d_wgrad(x, None, g_pre, C, ks)
+    N, Cin, H, W = x.shape
+    Gs = torch.empty((N, 9 * C, H, W), device=x.device, dtype=torch.float32)
+    L.call("rfn_tap_scatter_f32", L.dev(g_pre.contiguous()), L.dev(Gs), _i(N), _i(C), _i(H), _i(W))
+    gw = conv2d_wgrad(x, None, Gs, 9 * C, 1)  # [9C, Cin, 1, 1]
+    return gw.view(3, 3, C, Cin).permute(2, 3, 0, 1).contiguous()
+
+
 def conv_epilogue_bwd(y, gy, logs, ep_mode, act, want_gl=True):
     """in-place on gy: gy <- gu ; returns (gu, gb, gl)"""
     N, C = gy.shape[0], gy.shape[1]
@@ -270,7 +297,7 @@ class GlowStepFn(torch.autograd.Function):
         cin2 = cond if cond.shape[1] > 0 else None
         h1 = conv2d_raw(z1, cin2, pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b), f(n1l), act)
         h2 = conv2d_raw(h1, None, pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b), f(n2l), act)
-        o = conv2d_raw(h2, None, pack_weight(w3), C, int(w3.shape[2]), 2, f(b3), f(l3), 0)
+        o = zeros_conv_fwd(h2, w3, f(b3), f(l3))
         dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
         affine_coupling_(out, o, f(scale), f(scale_shift), dlogdet, clamp_type, False)
         ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o)
@@ -305,7 +332,7 @@ class GlowStepFn(torch.autograd.Function):
                _i(N), _i(C), _i(HW))
         # ---- conv3 (Conv2dZeros) bwd
         go, gb3, gl3 = conv_epilogue_bwd(o, go, f(l3), 2, 0)
-        gw3 = conv2d_wgrad(h2, None, go, C, int(w3.shape[2]))
+        gw3 = zeros_conv_wgrad(h2, go, C, int(w3.shape[2]))
         gh2 = conv2d_raw(go, None, pack_weight(w3, True), Hd, int(w3.shape[2]))
         # ---- actnorm2 + act bwd, conv2 (1x1) bwd
         gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, f(n2l), 1, act)
@@ -341,7 +368,7 @@ class GlowStepRevFn(torch.autograd.Function):
         cin2 = cond if cond.shape[1] > 0 else None
         h1 = conv2d_raw(z[:, :Ch], cin2, pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b), f(n1l), act)
         h2 = conv2d_raw(h1, None, pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b), f(n2l), act)
-        o = conv2d_raw(h2, None, pack_weight(w3), C, int(w3.shape[2]), 2, f(b3), f(l3), 0)
+        o = zeros_conv_fwd(h2, w3, f(b3), f(l3))
         dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
         affine_coupling_(z, o, f(scale), f(scale_shift), dlogdet, clamp_type, True)
         out = invconv_actnorm_rev(z, f(an_bias), f(an_logs), Winv.detach())

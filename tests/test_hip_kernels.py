@@ -196,3 +196,20 @@ def test_gauss_logp_fwd_bwd_sample(K, layout, std_mode):
     eps = torch.randn(N, Cz, H, W, generator=g)
     zs = K.gauss_sample(cu(o.detach()), cu(eps), layout, std_mode, 0.7)
     assert relerr(zs, (mean + std * 0.7 * eps)) < 1e-5
+
+
+@pytest.mark.parametrize("N,Cin,C,H,W", [(3, 40, 4, 8, 8), (2, 256, 8, 16, 16), (5, 24, 2, 3, 5)])
+def test_tap_expanded_zeros_conv_fwd_wgrad(K, N, Cin, C, H, W):
+    """Conv2dZeros with tiny Cout: 1x1 conv to 9C channels + tap gather == the 3x3 conv; scatter + 1x1 wgrad == wgrad"""
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(C, Cin, 3, 3, generator=g) * 0.1).requires_grad_(True)
+    b = torch.randn(C, generator=g) * 0.2
+    l = torch.randn(C, generator=g) * 0.1
+    ref = (F.conv2d(x, w, b, padding=1)) * torch.exp(3 * l).view(1, C, 1, 1)
+    gpre = torch.randn(N, C, H, W, generator=g)
+    F.conv2d(x, w, None, padding=1).backward(gpre)
+    o = K.zeros_conv_fwd(cu(x), cu(w.detach()), cu(b), cu(l))
+    assert relerr(o, ref) < 2e-5
+    gw = K.zeros_conv_wgrad(cu(x), cu(gpre), C, 3)
+    assert relerr(gw, w.grad) < 1e-4
