@@ -161,6 +161,26 @@ def parity_check(device):
             "rel_err": abs(bpd_gpu - bpd_ref) / abs(bpd_ref)}
 
 
+def supervise():
+    """Run the measurement in a child process: hipGraph mode first, and if that child dies (a crash inside a graph
+    capture cannot be caught in-process) once more in eager mode.  The parent never touches the GPU."""
+    import subprocess
+    base = [sys.executable, os.path.abspath(__file__)] + sys.argv[1:] + ["--child"]
+    rank = int(os.environ.get("RANK", 0))
+    for attempt, extra in enumerate(([], ["--no-graph"])):
+        if "--no-graph" in sys.argv and attempt == 1:
+            break
+        r = subprocess.run(base + extra, stdout=subprocess.PIPE, text=True)
+        lines = [l for l in (r.stdout or "").splitlines() if l.startswith("{")]
+        if r.returncode == 0 and (lines or rank != 0):
+            if lines:
+                print(lines[-1], flush=True)
+            return 0
+        print("[bench] child attempt %d failed (rc=%s)%s" % (attempt, r.returncode, "; retrying eager" if attempt == 0 else ""),
+              file=sys.stderr, flush=True)
+    return 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -170,6 +190,8 @@ def main():
     ap.add_argument("--frames", type=int, default=20)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-roofline", action="store_true")
+    ap.add_argument("--no-graph", action="store_true", help="eager launches instead of a captured hipGraph step")
+    ap.add_argument("--child", action="store_true", help=argparse.SUPPRESS)
     a = ap.parse_args()
 
     world = int(os.environ.get("WORLD_SIZE", 1))
@@ -182,7 +204,8 @@ def main():
     device = torch.device("cuda", local)
     if world > 1:
         # RFN_DIST_BACKEND=gloo + RFN_SINGLE_GPU=1: rehearsal of the N>1 path on a one-GPU box (all ranks on cuda:0)
-        dist.init_process_group(os.environ.get("RFN_DIST_BACKEND", "nccl"))
+        import datetime
+        dist.init_process_group(os.environ.get("RFN_DIST_BACKEND", "nccl"), timeout=datetime.timedelta(seconds=300))
     assert a.batch % world == 0, "global batch must divide over ranks"
     B_local = a.batch // world
 
@@ -198,17 +221,42 @@ def main():
     for i in range(max(a.warmup, 1)):
         solver.train_step(batches[i % 2])
     profile = rank == 0 and world == 1 and not a.no_roofline
-    barrier()
+    rec = None
     if profile:
-        rlib.PROFILE = []  # HIP events on the launch stream around every librfn_hip launch of the timed region
+        # kernel roofline: HIP events on the launch stream around every librfn_hip launch of eager training steps
+        # (identical kernels and shapes as the timed region; a captured graph cannot carry per-kernel events)
+        barrier()
+        rlib.PROFILE = []
+        for i in range(2):
+            solver.train_step(batches[i % 2])
+        torch.cuda.synchronize()
+        rec, rlib.PROFILE = rlib.PROFILE, None
+    graphed = False
+    if not a.no_graph:
+        graphed = solver.capture_graph(batches[0])
+        if world > 1:  # all ranks must agree on the mode
+            flag = torch.tensor([1 if graphed else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            if int(flag) == 0 and graphed:
+                solver._graph = None
+                solver.reducer.add_hooks()
+                graphed = False
+        if rank == 0:
+            print("[bench] hipGraph capture: %s %s" % ("ok" if graphed else "FAILED -> eager",
+                                                      "" if graphed else getattr(solver, "_graph_error", "")),
+                  file=sys.stderr, flush=True)
+        if graphed:
+            solver.train_step(batches[0])  # first replay outside the timed region
+    barrier()
     t0 = time.perf_counter()
     for i in range(a.steps):
         solver.train_step(batches[i % 2])
     barrier()
     dt = time.perf_counter() - t0
-    rec, rlib.PROFILE = rlib.PROFILE, None
+    solver.flush_log()
     if rank == 0:
-        print("[bench] timed region done: %.1f ms/step" % (1e3 * dt / a.steps), file=sys.stderr, flush=True)
+        print("[bench] timed region done: %.1f ms/step (%s)" % (1e3 * dt / a.steps, "graph" if graphed else "eager"),
+              file=sys.stderr, flush=True)
     if world > 1:
         t = torch.tensor([dt], device=device, dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -223,10 +271,11 @@ def main():
            "config": {"workload": "RFN SM-MNIST 64x64 canonical (K=10 L=5 Hd=256 h=200 z=56), global_batch=%d, "
                                   "seq_len=%d, train step" % (a.batch, a.frames),
                       "global_batch": a.batch, "seq_len": a.frames, "parallelism": "dp%d" % world},
-           "modeled_frames_per_s": a.batch * (a.frames - 1) * a.steps / dt, "bits_per_dim_last_step": bpd}
+           "modeled_frames_per_s": a.batch * (a.frames - 1) * a.steps / dt, "bits_per_dim_last_step": bpd,
+           "launch_mode": "hipGraph replay (fwd+bwd captured)" if graphed else "eager"}
     if rank == 0 and world == 1:
         if profile:
-            roof, table = kernel_roofline(rec, a.steps)
+            roof, table = kernel_roofline(rec, 2)
             out["roofline"] = roof
             os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
             with open(os.path.join(ROOT, "gpurun_out", "bench_kernel_table.json"), "w") as f:
@@ -242,4 +291,7 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    if "--child" in sys.argv or os.environ.get("RFN_BENCH_NO_SUPERVISOR") == "1":
+        main()
+    else:
+        sys.exit(supervise())

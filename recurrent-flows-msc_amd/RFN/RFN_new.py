@@ -12,11 +12,19 @@ Data dependent ActNorm initialisation uses the first B frames (t = 1) exactly li
 """
 import torch
 import torch.nn as nn
-import torch.distributions as td
 
 from Flow import ListGlow
 from Flow.glow_modules import ActNorm
 from Utils import VGG_upscaler, VGG_downscaler, SimpleParamNet, ConvLSTM, free_bits_kl, batch_reduce
+
+
+def kl_normal(q_mean, q_std, p_mean, p_std):
+    """KL(N(q) || N(p)) element-wise — the closed form torch.distributions.kl_divergence evaluates for two Normals
+    (RFN_new.py:206-207,236), written out so that no distribution object validates its arguments with a host sync
+    (which would also make the step impossible to capture into a hipGraph)."""
+    var_ratio = (q_std / p_std) ** 2
+    t1 = ((q_mean - p_mean) / p_std) ** 2
+    return 0.5 * (var_ratio + t1 - 1 - var_ratio.log())
 
 
 class RFN(nn.Module):
@@ -169,7 +177,7 @@ class RFN(nn.Module):
             if draws is not None:
                 noise_t.append(draws.pop(0).to(dev))
             if self.D == 1:
-                kl_loss = kl_loss + td.kl_divergence(td.Normal(enc_mean, enc_std), td.Normal(prior_mean, prior_std))
+                kl_loss = kl_loss + kl_normal(enc_mean, enc_std, prior_mean, prior_std)
             zprev, zxprev = zt, zxt
 
         # ---- the decoder: all B*(T-1) frames in one call, t-major
@@ -205,8 +213,7 @@ class RFN(nn.Module):
                     em, es = st_mean[idt + d], st_std[idt + d]
                     if d > 0:
                         em, es = em.detach().clone(), es.detach().clone()
-                    overshot_loss = overshot_loss + self.overshot_w * td.kl_divergence(td.Normal(em, es),
-                                                                                        td.Normal(pm, ps))
+                    overshot_loss = overshot_loss + self.overshot_w * kl_normal(em, es, pm, ps)
                 kl_loss = kl_loss + 1 / D * overshot_loss
 
         kl_free_bit = free_bits_kl(kl_loss, free_bits=self.free_bits) if self.free_bits > 0 else kl_loss

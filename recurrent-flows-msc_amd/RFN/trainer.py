@@ -126,8 +126,10 @@ class Solver(object):
     # ---------------------------------------------------------------------------------------------- loop
     def train_step(self, image):
         """one optimizer step on an already-resident [B,T,C,H,W] batch in [0,1] (RFN/trainer.py:237-250)."""
-        image = self.preprocess(image)
         self.beta = min(self.beta_max, self.beta_min + self.counter * (self.beta_max - self.beta_min) / self.beta_steps)
+        if self._graph is not None:
+            return self._graphed_step(image)
+        image = self.preprocess(image)
         first = self.counter == 0 and self.world > 1
         kl_free_bit, kl, nll = self.model.loss(image, 0)
         if first:  # replicas must share rank 0's data dependent ActNorm init: broadcast, then redo the step's forward
@@ -142,6 +144,81 @@ class Solver(object):
             self.adjust_learning_rate(self.counter)
         self.counter += 1
         return loss
+
+    # ---- hipGraph mode: preprocess + loss forward + backward of one step are captured once and replayed, which removes
+    # the ~7000 per-step launches' host cost (the step is launch-bound once the batch is sharded over several GPUs).
+    # Gradient all-reduce, Adam, the beta/LR schedules and the loss bookkeeping stay outside the graph.
+    _graph = None
+
+    def capture_graph(self, example_image, static_draws=None):
+        """Call after a few eager steps (ActNorm initialised, MIOpen solvers chosen).  Returns True on success; on
+        any capture failure the solver silently stays in eager mode.  `static_draws` (tests only) pins the noise.
+        The caller must not hold tensors of an earlier eager step's autograd graph (e.g. a returned loss): their
+        AccumulateGrad nodes are bound to the default stream and would pull it into the capture."""
+        if not torch.cuda.is_available():
+            return False
+        try:
+            self._g_draws = static_draws
+            self._g_in = example_image.clone()
+            self._g_beta = torch.zeros((), device=example_image.device)
+            self.reducer.remove_hooks()           # reductions run after the replay, on the static gradient tensors
+            self.optimizer.zero_grad(set_to_none=True)
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                # three warm-ups of exactly the captured callable on a side stream: MIOpen / the autograd engine still
+                # initialise lazily on the 2nd-3rd execution of a backward, and doing that under capture crashes
+                for _ in range(3):
+                    self._graph_body()
+                    self.optimizer.zero_grad(set_to_none=True)
+            torch.cuda.current_stream().wait_stream(side)
+            self.optimizer.zero_grad(set_to_none=True)
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._graph_body()
+            self._graph = g
+            return True
+        except Exception as e:  # noqa: BLE001 - any failure means "no graph", never a dead trainer
+            import traceback
+            self._graph = None
+            self._graph_error = repr(e)[:200] + " | " + " <- ".join(
+                "%s:%d %s" % (f.filename.split("/")[-1], f.lineno, f.name) for f in traceback.extract_tb(e.__traceback__)[-6:])
+            torch.cuda.synchronize()
+            self.reducer.add_hooks()
+            self.optimizer.zero_grad(set_to_none=True)
+            return False
+
+    def _graph_body(self):
+        image = self.preprocess(self._g_in)
+        kl_free_bit, kl, nll = self.model.loss(image, 0, draws=getattr(self, "_g_draws", None))
+        loss = nll + self._g_beta * kl_free_bit
+        loss.backward()
+        self._g_out = torch.stack([loss.detach(), kl_free_bit.detach(), kl.detach(), nll.detach()])
+
+    def _graphed_step(self, image):
+        self._g_in.copy_(image, non_blocking=True)
+        self._g_beta.fill_(self.beta)
+        self._graph.replay()
+        self.reducer.finish()
+        self.optimizer.step()
+        if self.scheduler_type == "linear":
+            self.adjust_learning_rate(self.counter)
+        self.counter += 1
+        self._pending_log = (self._g_out, tuple(image.shape))
+        return self._g_out[0]
+
+    def flush_log(self):
+        """bits/dim bookkeeping of the last graphed step (one device->host read, kept off the per-step path)."""
+        if getattr(self, "_pending_log", None) is None:
+            return
+        out, shape = self._pending_log
+        loss, _, kl, nll = [float(v) for v in out.tolist()]
+        t = shape[1] - 1
+        self.bits.append((kl + nll) / (np.log(2.) * float(np.prod(shape[2:])) * t))
+        self.losses.append(loss / t)
+        self.kl_loss.append(kl / t)
+        self.recon_loss.append(nll / t)
+        self._pending_log = None
 
     def train(self):
         max_steps = getattr(self.args, "max_steps", 0)

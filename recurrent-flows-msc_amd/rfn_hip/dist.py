@@ -48,10 +48,19 @@ class GradBucketReducer:
         self._works = []
         self._flat = [None] * len(self.buckets)
         self._hooks = []
-        if self.world > 1:
+        self.add_hooks()
+        self.reset()
+
+    def add_hooks(self):
+        if self.world > 1 and not self._hooks:
             for p in self.params:
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._on_grad))
-        self.reset()
+
+    def remove_hooks(self):
+        """no overlap with backward: finish() then reduces every bucket after the fact (hipGraph-replayed backward)."""
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []
 
     def reset(self):
         self._pending = [len(b) for b in self.buckets]

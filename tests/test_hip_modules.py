@@ -262,3 +262,51 @@ def test_rfn_loss_end_to_end(golden, name):
     (nll + 0.3 * kl_fb).backward()
     grads_close(m, {k: v for k, v in f["grads"].items() if not k.startswith(("extractor.net.", "upscaler.net."))
                     and "LSTMlayer.Wc" not in k}, 5e-3, 5e-4)
+
+
+def test_graph_captured_step_equals_eager_step():
+    """Solver in hipGraph mode (fwd+bwd captured, replayed) produces the same loss and gradients as the eager step."""
+    import __graft_entry__ as ge
+    from RFN.trainer import Solver
+    from RFN import RFN
+    from rfn_hip import dist as rdist
+    args = ge._tiny_args()
+    for k, v in dict(n_bits=8, n_epochs=1, learning_rate=0.0, verbose=False, path="/gpurun_out/tmp/", patience_lr=1,
+                     factor_lr=0.5, min_lr=0.0, patience_es=1, beta_max=0.5, beta_min=0.5, beta_steps=10,
+                     choose_data="mnist", n_frames=4, digit_size=28, step_length=4, num_digits=2, image_size=16,
+                     preprocess_range="0.5", preprocess_scale=255, num_workers=0, multigpu=False, n_predictions=2,
+                     n_conditions=2, scheduler_type="linear", use_validation_set=False).items():
+        setattr(args, k, v)
+    torch.manual_seed(3)
+    s = Solver(args)
+    s.device = torch.device("cuda")
+    s.model = RFN(args).cuda().train()
+    s.reducer = rdist.GradBucketReducer(list(s.model.named_parameters()))
+    s.optimizer = torch.optim.SGD(s.model.parameters(), lr=0.0)  # parameters stay fixed: both modes see the same model
+    g = torch.Generator().manual_seed(4)
+    B, T = args.batch_size, 4
+    x = torch.rand(B, T, 1, 16, 16, generator=g).cuda()
+    draws = []
+    for _ in range(T - 1):
+        draws += [torch.randn(B, args.z_dim, 4, 4, generator=g).cuda(), torch.randn(B, args.z_dim, 4, 4, generator=g).cuda(),
+                  (torch.rand(B, 1, 16, 16, generator=g) / 256).cuda()]
+    s.model.loss(s.preprocess(x), 0, draws=draws)  # data dependent init
+    s.beta = 0.5
+    kl_fb, kl, nll = s.model.loss(s.preprocess(x), 0, draws=draws)
+    s.optimizer.zero_grad(set_to_none=True)
+    (nll + 0.5 * kl_fb).backward()
+    eager = {n: p.grad.detach().clone() for n, p in s.model.named_parameters() if p.grad is not None}
+    eager_loss = float(nll + 0.5 * kl_fb)
+    # drop every reference to the eager autograd graph: its AccumulateGrad nodes are bound to the default stream and
+    # would drag that stream into the capture (the trainer never keeps a loss tensor across steps either)
+    del kl_fb, kl, nll
+    s.optimizer.zero_grad(set_to_none=True)
+    assert s.capture_graph(x, static_draws=draws), getattr(s, "_graph_error", "")
+    for _ in range(2):  # replay twice: gradients must be overwritten, not accumulated
+        out = s.train_step(x)
+    torch.cuda.synchronize()
+    assert abs(float(out) - eager_loss) <= 1e-5 * abs(eager_loss)
+    for n, p in s.model.named_parameters():
+        if n in eager:
+            torch.testing.assert_close(p.grad, eager[n], rtol=1e-4, atol=1e-5 * float(eager[n].abs().max()) + 1e-7,
+                                       msg=lambda m: n + ": " + m)
