@@ -673,7 +673,10 @@ static void launch_wgrad_bpx(WgradParams& p, hipStream_t s) {
 // tiny maps (<= 4x4) use 64-pixel tiles: their zero-padded LDS image is 2.25-4x the tile, and 128 would not fit.
 template <int KS, int WCO, int WCI, int TCO, int TCI>
 static void launch_wgrad(WgradParams& p, hipStream_t s) {
-    if (p.H * p.W <= 16)
+    // 64-pixel stages everywhere: the G+X stage then takes <= ~66 KB of LDS, so 2-3 workgroups share a CU and one's
+    // staging overlaps another's MFMAs (128-pixel stages left a single workgroup per CU: 57 -> 70 TFLOP/s on conv2)
+    static int use128 = getenv("RFN_WGRAD_BPX128") ? atoi(getenv("RFN_WGRAD_BPX128")) : 0;
+    if (p.H * p.W <= 16 || !use128)
         launch_wgrad_bpx<KS, WCO, WCI, TCO, TCI, 64>(p, s);
     else
         launch_wgrad_bpx<KS, WCO, WCI, TCO, TCI, 128>(p, s);

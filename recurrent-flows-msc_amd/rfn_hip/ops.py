@@ -125,7 +125,9 @@ def wgrad_kernel_name(Cout, Cin, ks, HW):
         cfg = "4,1,1,1" if Cin <= 32 else ("1,4,1,1" if Cout <= 32 else "2,2,1,1")
     else:
         cfg = "4,1,2,1" if Cin <= 32 else ("1,4,1,2" if Cout <= 32 else "2,2,2,2")
-    return "wgrad_mfma_kernel<%d,%s,%d>" % (ks, cfg, 64 if HW <= 16 else 128)
+    if ks == 1 and 32 < Cout <= 64 and Cin > 32:
+        cfg = "1,4,2,2"
+    return "wgrad_mfma_kernel<%d,%s,64>" % (ks, cfg)
 
 
 def conv2d_wgrad(in1, in2, g, Cout, ks):
