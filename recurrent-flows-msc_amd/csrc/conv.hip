@@ -102,7 +102,10 @@ extern "C" int rfn_pack_conv_weight_f32(const float* w, float* wpk, int Cout, in
 
 // ------------------------------------------------------------------------------------------------ forward / dgrad
 template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
-__global__ __launch_bounds__(256) void conv_mfma_kernel(const ConvParams p) {
+#ifndef RFN_CONV_WAVES
+#define RFN_CONV_WAVES 1
+#endif
+__global__ __launch_bounds__(256, RFN_CONV_WAVES) void conv_mfma_kernel(const ConvParams p) {
     constexpr int T = KS * KS, PAD = KS / 2;
     constexpr int BCO = 32 * TCO * WCO;
     static_assert(WCO * WPX == 4, "4 waves");

@@ -54,15 +54,38 @@ def actnorm_invconv_fwd(x, bias, logs, Wm):
     return z
 
 
-def actnorm_invconv_bwd(x, bias, logs, Wm, gz):
+class ZeroArena:
+    """one zero-filled allocation handed out in slices: the accumulate-into outputs of a backward node (weight
+    gradients, per-channel sums) share ONE fill launch instead of one torch.zeros each."""
+
+    def __init__(self, numel, device):
+        self.buf = torch.zeros(int(numel), device=device, dtype=torch.float32)
+        self.off = 0
+
+    def take(self, *shape):
+        n = 1
+        for d in shape:
+            n *= int(d)
+        n_al = (n + 3) // 4 * 4  # keep every slice 16-byte aligned
+        assert self.off + n <= self.buf.numel(), "ZeroArena exhausted"
+        t = self.buf[self.off:self.off + n].view(*shape)
+        self.off += n_al
+        return t
+
+
+def _zeros(arena, *shape, device=None):
+    return arena.take(*shape) if arena is not None else torch.zeros(shape, device=device, dtype=torch.float32)
+
+
+def actnorm_invconv_bwd(x, bias, logs, Wm, gz, arena=None):
     N, C = x.shape[0], x.shape[1]
     xp, xns = L.frames(x, "x")
     gzp, gzns = L.frames(gz, "gz")
     gx = torch.empty(x.shape, device=x.device, dtype=x.dtype)
     gxp, gxns = L.frames(gx, "gx")
-    gW = torch.zeros((C, C), device=x.device, dtype=torch.float32)
-    gb = torch.zeros(C, device=x.device, dtype=torch.float32)
-    gl = torch.zeros(C, device=x.device, dtype=torch.float32)
+    gW = _zeros(arena, C, C, device=x.device)
+    gb = _zeros(arena, C, device=x.device)
+    gl = _zeros(arena, C, device=x.device)
     L.call("rfn_actnorm_invconv_bwd_f32", xp, _l(xns), L.dev(bias.contiguous()), L.dev(logs.contiguous()),
            L.dev(Wm.contiguous()), gzp, _l(gzns), gxp, _l(gxns), L.dev(gW), L.dev(gb), L.dev(gl), _i(N), _i(C),
            _i(_hw(x)))
@@ -130,7 +153,7 @@ def wgrad_kernel_name(Cout, Cin, ks, HW):
     return "wgrad_mfma_kernel<%d,%s,64>" % (ks, cfg)
 
 
-def conv2d_wgrad(in1, in2, g, Cout, ks):
+def conv2d_wgrad(in1, in2, g, Cout, ks, arena=None):
     """returns gw [Cout, Cin, ks, ks]"""
     N, C1, H, W = in1.shape
     C2 = 0 if in2 is None else int(in2.shape[1])
@@ -138,11 +161,13 @@ def conv2d_wgrad(in1, in2, g, Cout, ks):
     i1p, i1ns = L.frames(in1, "in1")
     i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
     gp, gns = L.frames(g, "g")
-    gwt = torch.zeros((ks * ks, Cout, Cin), device=in1.device, dtype=torch.float32)
+    gwt = _zeros(arena, ks * ks, Cout, Cin, device=in1.device)
     L.call("rfn_conv2d_wgrad_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), gp, _l(gns), _i(Cout), L.dev(gwt),
            _i(N), _i(H), _i(W), _i(ks),
            meta=("wgrad", wgrad_kernel_name(Cout, Cin, ks, H * W), 2.0 * N * H * W * Cin * Cout * ks * ks,
                  "N%d %d->%d %dx%d k%d" % (N, Cin, Cout, H, W, ks)))
+    if ks == 1:
+        return gwt.view(Cout, Cin, 1, 1)  # tap-major == torch layout when there is a single tap
     gw = torch.empty((Cout, Cin, ks, ks), device=in1.device, dtype=torch.float32)
     L.call("rfn_wgrad_finish_f32", L.dev(gwt), L.dev(gw), _i(Cout), _i(Cin), _i(ks), _i(0))
     return gw
@@ -164,24 +189,24 @@ def zeros_conv_fwd(x, w, b, logs):
     return o
 
 
-def zeros_conv_wgrad(x, g_pre, C, ks):
+def zeros_conv_wgrad(x, g_pre, C, ks, arena=None):
     """weight gradient of the conv inside Conv2dZeros given g_pre = grad wrt (conv + b); same switch as the forward."""
     if ks != 3 or C > TAP_MAX_COUT:
-        return conv2d_wgrad(x, None, g_pre, C, ks)
+        return conv2d_wgrad(x, None, g_pre, C, ks, arena)
     N, Cin, H, W = x.shape
     Gs = torch.empty((N, 9 * C, H, W), device=x.device, dtype=torch.float32)
     L.call("rfn_tap_scatter_f32", L.dev(g_pre.contiguous()), L.dev(Gs), _i(N), _i(C), _i(H), _i(W))
-    gw = conv2d_wgrad(x, None, Gs, 9 * C, 1)  # [9C, Cin, 1, 1]
+    gw = conv2d_wgrad(x, None, Gs, 9 * C, 1, arena)  # [9C, Cin, 1, 1]
     return gw.view(3, 3, C, Cin).permute(2, 3, 0, 1).contiguous()
 
 
-def conv_epilogue_bwd(y, gy, logs, ep_mode, act, want_gl=True):
+def conv_epilogue_bwd(y, gy, logs, ep_mode, act, want_gl=True, arena=None):
     """in-place on gy: gy <- gu ; returns (gu, gb, gl)"""
     N, C = gy.shape[0], gy.shape[1]
     yp, yns = (None, 0) if y is None else L.frames(y, "y")
     gp, gns = L.frames(gy, "gy")
-    gb = torch.zeros(C, device=gy.device, dtype=torch.float32)
-    gl = torch.zeros(C, device=gy.device, dtype=torch.float32) if want_gl else None
+    gb = _zeros(arena, C, device=gy.device)
+    gl = _zeros(arena, C, device=gy.device) if want_gl else None
     L.call("rfn_conv_epilogue_bwd_f32", yp, _l(yns), gp, _l(gns), gp, _l(gns), L.dev(logs), L.dev(gb), L.dev(gl),
            _i(N), _i(C), _i(_hw(gy)), _i(ep_mode), _i(act))
     return gy, gb, gl
@@ -317,13 +342,18 @@ class GlowStepFn(torch.autograd.Function):
         f = lambda t: None if t is None else t.detach().reshape(-1).contiguous()
         gout = gout.contiguous()
         gdl = None if gdl is None else gdl.contiguous()
+        Cc = int(cond.shape[1])
+        k1, k2, k3 = int(w1.shape[2]), int(w2.shape[2]), int(w3.shape[2])
+        # every accumulate-into output of this node lives in one zero-filled arena (1 fill launch instead of 14)
+        arena = ZeroArena(2 * Ch + 8 + 3 * 2 * (Hd + 4) + 2 * (C + 4) + k1 * k1 * Hd * (Ch + Cc) + k2 * k2 * Hd * Hd
+                          + max(k3 * k3 * C * Hd, 9 * C * Hd) + C * C + 2 * C + 64, dev)
         # ---- affine bwd: gz (z1 half = gout z1 half, z2 half computed), go
         gz = gout.clone()
         go = torch.empty_like(o)
         gscale = gshift = None
         if clamp_type == 0:
-            gscale = torch.zeros(Ch, device=dev, dtype=torch.float32)
-            gshift = torch.zeros(Ch, device=dev, dtype=torch.float32)
+            gscale = arena.take(Ch)
+            gshift = arena.take(Ch)
         op, ons = L.frames(o, "o")
         outp, outns = L.frames(out, "out")
         gop, gons = L.frames(gout, "gout")
@@ -333,23 +363,23 @@ class GlowStepFn(torch.autograd.Function):
                L.dev(f(scale_shift)), gzp, _l(gzns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), _i(clamp_type),
                _i(N), _i(C), _i(HW))
         # ---- conv3 (Conv2dZeros) bwd
-        go, gb3, gl3 = conv_epilogue_bwd(o, go, f(l3), 2, 0)
-        gw3 = zeros_conv_wgrad(h2, go, C, int(w3.shape[2]))
-        gh2 = conv2d_raw(go, None, pack_weight(w3, True), Hd, int(w3.shape[2]))
+        go, gb3, gl3 = conv_epilogue_bwd(o, go, f(l3), 2, 0, arena=arena)
+        gw3 = zeros_conv_wgrad(h2, go, C, k3, arena)
+        gh2 = conv2d_raw(go, None, pack_weight(w3, True), Hd, k3)
         # ---- actnorm2 + act bwd, conv2 (1x1) bwd
-        gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, f(n2l), 1, act)
-        gw2 = conv2d_wgrad(h1, None, gh2, Hd, int(w2.shape[2]))
-        gh1 = conv2d_raw(gh2, None, pack_weight(w2, True), Hd, int(w2.shape[2]))
+        gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, f(n2l), 1, act, arena=arena)
+        gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
+        gh1 = conv2d_raw(gh2, None, pack_weight(w2, True), Hd, k2)
         # ---- actnorm1 + act bwd, conv1 bwd (grad flows to z1 (accumulated into gz's first half) and to cond)
-        gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, f(n1l), 1, act)
+        gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, f(n1l), 1, act, arena=arena)
         z1 = out[:, :Ch]
         has_cond = cond.shape[1] > 0
-        gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, int(w1.shape[2]))
+        gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
         gcond = torch.empty_like(cond) if has_cond else torch.zeros_like(cond)
         conv2d_raw(gh1, None, pack_weight(w1, True), Ch + int(cond.shape[1]), int(w1.shape[2]), 0, None, None, 0,
                    out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True, acc2=False)
         # ---- invconv + actnorm bwd
-        gx, gW, gab, gal = actnorm_invconv_bwd(x, f(an_bias), f(an_logs), Wm.detach(), gz)
+        gx, gW, gab, gal = actnorm_invconv_bwd(x, f(an_bias), f(an_logs), Wm.detach(), gz, arena)
         return (gx, gcond, gW, gab.view(an_bias.shape), gal.view(an_logs.shape), gw1, gn1b.view(1, -1, 1, 1),
                 gn1l.view(n1l.shape), gw2, gn2b.view(1, -1, 1, 1), gn2l.view(n2l.shape), gw3, gb3, gl3.view(l3.shape),
                 None if gscale is None else gscale.view(scale.shape),
