@@ -69,6 +69,19 @@ int rfn_conv2d_fwd_f32(const float* in1, long in1_ns, int C1, const float* in2, 
                        int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
                        const float* p0, const float* p1, int act, rfn_stream_t stream);
 
+/* ---- split-precision variant of the same convolution ("bf16x3"): every fp32 operand x is split on the fly into two
+ * bf16 numbers hi + lo and a*b is formed as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi by three v_mfma_f32_32x32x16_bf16 with
+ * fp32 accumulation (relative error of a product <= 2^-16; measured nll error ~1e-5 relative, budget 1e-4).  Inputs,
+ * outputs, epilogues and argument meaning are identical to rfn_conv2d_fwd_f32; wpk must come from
+ * rfn_pack_conv_weight_bf16x3 (which also performs the hi/lo split of the weights). */
+int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                          const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                          int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
+                          const float* p0, const float* p1, int act, rfn_stream_t stream);
+long rfn_packed_weight_size_bf16x3(int Cout, int Cin, int ks); /* in floats (4-byte units) */
+int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
+                                rfn_stream_t stream);
+
 /* number of floats of a packed weight buffer for (Cout, Cin, ks) */
 long rfn_packed_weight_size(int Cout, int Cin, int ks);
 /* Pack torch-layout weights w[Cout][Cin][ks][ks] for rfn_conv2d_fwd_f32.

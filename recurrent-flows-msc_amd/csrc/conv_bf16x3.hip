@@ -1,0 +1,376 @@
+// Split-precision ("bf16x3") implicit-GEMM convolution for gfx950.
+//
+// fp32 MFMA (v_mfma_f32_32x32x2_f32) runs at 1/16 of the bf16 MFMA rate.  Every fp32 operand is split into two bf16
+// numbers  x = hi + lo  (hi = RNE_bf16(x), lo = RNE_bf16(x - hi), 16 significant bits together) and the product is
+// formed as  a*b ≈ a_hi*b_hi + a_hi*b_lo + a_lo*b_hi  with three v_mfma_f32_32x32x16_bf16 accumulating in fp32
+// (the dropped a_lo*b_lo term is ≤ 2^-16 relative).  Measured on the oracle (tools/ notes in DESIGN.md): the nll /
+// bits-per-dim error against an fp64 reference is ~1e-5 relative — ten times the plain fp32 error and a tenth of the
+// 1e-4 budget — for 3/16 of the fp32-MFMA cycles.
+//
+// Same GEMM orientation, pixel tiling, halo staging, descriptors, register prefetch, split-K and epilogue as conv.hip
+// (D[cout][pixel], C/D register layout is dtype independent).  What differs is the LDS image: an MFMA operand lane
+// needs 8 consecutive k (channels) of one row/column in one 16-byte register quad, so activations are stored as
+// [plane hi|lo][8-channel group][slot][8 x bf16] and weights (pre-split on the device by the pack kernel) as
+// [iteration][plane][k-group][cout][8 x bf16]; both fragments are single ds_read_b128.
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+static inline void packed_dims_b3(int Cout_l, int Cin_l, int* CoutP, int* Cin16) {
+    *CoutP = ((Cout_l + 127) / 128) * 128;
+    *Cin16 = (Cin_l + 15) / 16;
+}
+
+// packed unit (16 bytes = 8 bf16) index: (((c16*T + tap)*2 + plane)*2 + g)*CoutP + co ; element j <-> cin = c16*16+g*8+j
+__global__ void pack_weight_b3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wpk, int Cout, int Cin, int KS,
+                                      int CoutP, int Cin16, int transpose_flip) {
+    const int T = KS * KS;
+    const int Co_l = transpose_flip ? Cin : Cout;
+    const int Ci_l = transpose_flip ? Cout : Cin;
+    const long total = (long)Cin16 * T * 2 * CoutP;  // (hi, lo) pairs of units
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % CoutP);
+        long r = idx / CoutP;
+        const int g = (int)(r & 1);
+        r >>= 1;
+        const int tap = (int)(r % T);
+        const int c16 = (int)(r / T);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = c16 * 16 + g * 8 + j;
+            float v = 0.f;
+            if (co < Co_l && ci < Ci_l)
+                v = transpose_flip ? w[((long)ci * Cin + co) * T + (T - 1 - tap)] : w[((long)co * Cin + ci) * T + tap];
+            const __bf16 h = (__bf16)v;
+            hi[j] = h;
+            lo[j] = (__bf16)(v - (float)h);
+        }
+        const long base = ((long)(c16 * T + tap) * 2) * 2 * CoutP;
+        wpk[base + (long)(0 * 2 + g) * CoutP + co] = hi;
+        wpk[base + (long)(1 * 2 + g) * CoutP + co] = lo;
+    }
+}
+
+extern "C" long rfn_packed_weight_size_bf16x3(int Cout, int Cin, int ks) {
+    // in FLOATS (4 bytes), large enough for both orientations
+    int a, b, c, d;
+    packed_dims_b3(Cout, Cin, &a, &b);
+    packed_dims_b3(Cin, Cout, &c, &d);
+    long s0 = (long)b * ks * ks * 4 * a * 4, s1 = (long)d * ks * ks * 4 * c * 4;  // units * 16 B / 4 B
+    return s0 > s1 ? s0 : s1;
+}
+
+extern "C" int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
+                                           rfn_stream_t stream) {
+    RFN_CHECK_ARG(w && wpk && Cout > 0 && Cin > 0 && (ks == 1 || ks == 3), -1);
+    RFN_CHECK_ARG(((uintptr_t)wpk & 15) == 0, -2);
+    int CoutP, Cin16;
+    if (!transpose_flip)
+        packed_dims_b3(Cout, Cin, &CoutP, &Cin16);
+    else
+        packed_dims_b3(Cin, Cout, &CoutP, &Cin16);
+    long total = (long)Cin16 * ks * ks * 2 * CoutP;
+    int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
+    hipLaunchKernelGGL(pack_weight_b3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
+                       reinterpret_cast<bf16x8*>(wpk), Cout, Cin, ks, CoutP, Cin16, transpose_flip);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
+__global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
+    constexpr int T = KS * KS, PAD = KS / 2;
+    constexpr int BCO = 32 * TCO * WCO, BPX = 32 * TPX * WPX;
+    constexpr int NG = KC / 8;    // 8-channel groups per chunk
+    constexpr int NS = KC / 16;   // k16 steps per chunk and tap
+    static_assert(WCO * WPX == 4 && KC % 16 == 0, "4 waves, whole k16 steps");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wco = wave / WPX, wpx = wave % WPX;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int HW = p.H * p.W;
+    const int Cin = p.C1 + p.C2;
+
+    int pt = blockIdx.x;
+    const int wt = pt % p.n_wtiles;
+    pt /= p.n_wtiles;
+    const int ht = pt % p.n_htiles;
+    const int ft = pt / p.n_htiles;
+    const int x0 = wt * p.TWp, y0 = ht * p.TH, f0 = ft * p.TF;
+    const int RW = p.TWp + 2 * PAD, RH = p.TH + 2 * PAD;
+    const int FRM = RH * RW, IMG = p.TF * FRM;
+    const int co_base = blockIdx.y * BCO + wco * (32 * TCO);
+
+    // LDS: Bs[plane][NG][IMG] units | Ws[NS*T][plane][2][BCO] units | ep[2][BCO] floats
+    bf16x8* Bs = reinterpret_cast<bf16x8*>(lds_raw);
+    bf16x8* Ws = Bs + 2 * NG * IMG;
+    float* ep = reinterpret_cast<float*>(Ws + NS * T * 4 * BCO);
+
+    int lds_off[TPX], pn[TPX], ppix[TPX];
+    bool pvalid[TPX];
+#pragma unroll
+    for (int t = 0; t < TPX; ++t) {
+        const int q = (wpx * TPX + t) * 32 + l31;
+        const int col = q & (p.TWp - 1);
+        const int row = (q >> p.tw_shift) & (p.TH - 1);
+        const int f = q >> (p.tw_shift + p.th_shift);
+        lds_off[t] = f * FRM + row * RW + col;
+        pvalid[t] = (x0 + col < p.W) && (y0 + row < p.H) && (f0 + f < p.N);
+        pn[t] = f0 + f;
+        ppix[t] = (y0 + row) * p.W + x0 + col;
+    }
+
+    f32x16 acc[TCO][TPX];
+#pragma unroll
+    for (int a = 0; a < TCO; ++a)
+#pragma unroll
+        for (int t = 0; t < TPX; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][t][r] = 0.f;
+
+    // ---- activation staging descriptors (as in conv.hip): thread -> image slot(s), 8-channel group phase
+    constexpr int NPOS = (KS == 1) ? 1 : (BPX >= 256 ? 4 : (BPX >= 128 ? 2 : 1));
+    constexpr int GROUPS = (KS == 1 && BPX < 256) ? (BPX >= 64 ? 256 / BPX : 4) : 1;
+    constexpr int P2 = 256 / GROUPS;
+    constexpr int NGT = (NG + GROUPS - 1) / GROUPS;  // channel groups per thread
+    const int slot = tid & (P2 - 1);
+    const int phase = __builtin_amdgcn_readfirstlane(tid / P2);
+    int soff1[NPOS], soff2[NPOS];
+    bool sok[NPOS], sin[NPOS];
+#pragma unroll
+    for (int j = 0; j < NPOS; ++j) {
+        const int r = slot + P2 * j;
+        sin[j] = r < IMG;
+        const int f = r / FRM;
+        const int rr = r - f * FRM;
+        const int yy = rr / RW;
+        const int xx = rr - yy * RW;
+        const int gy = y0 + yy - PAD, gx = x0 + xx - PAD;
+        sok[j] = sin[j] && (f0 + f < p.N) && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        soff1[j] = sok[j] ? (int)(f * p.in1_ns) + gy * p.W + gx : 0;
+        soff2[j] = sok[j] ? (int)(f * p.in2_ns) + gy * p.W + gx : 0;
+    }
+    const float* in1b = p.in1 + (long)f0 * p.in1_ns;
+    const float* in2b = p.in2 ? p.in2 + (long)f0 * p.in2_ns : p.in1;
+    float stg[NGT][NPOS][8];
+    auto prefetch = [&](int chunk) {
+#pragma unroll
+        for (int i = 0; i < NGT; ++i) {
+            const int gi = phase + GROUPS * i;  // scalar: 8-channel group inside the chunk
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ch = chunk * KC + gi * 8 + c;
+                const bool chv = gi < NG && ch < Cin;
+                const int chc = chv ? ch : 0;
+                const bool first = chc < p.C1;
+                const float* src = first ? in1b + (long)chc * HW : in2b + (long)(chc - p.C1) * HW;
+#pragma unroll
+                for (int j = 0; j < NPOS; ++j) {
+                    const float v = src[first ? soff1[j] : soff2[j]];
+                    stg[i][j][c] = (sok[j] && chv) ? v : 0.f;
+                }
+            }
+        }
+    };
+    auto commit = [&]() {  // split to (hi, lo) and store the two 16-byte units
+#pragma unroll
+        for (int i = 0; i < NGT; ++i) {
+            const int gi = phase + GROUPS * i;
+            if (gi < NG) {
+#pragma unroll
+                for (int j = 0; j < NPOS; ++j) {
+                    if (sin[j]) {
+                        bf16x8 hi, lo;
+#pragma unroll
+                        for (int c = 0; c < 8; ++c) {
+                            const float v = stg[i][j][c];
+                            const __bf16 h = (__bf16)v;
+                            hi[c] = h;
+                            lo[c] = (__bf16)(v - (float)h);
+                        }
+                        const int r = slot + P2 * j;
+                        Bs[(0 * NG + gi) * IMG + r] = hi;
+                        Bs[(1 * NG + gi) * IMG + r] = lo;
+                    }
+                }
+            }
+        }
+    };
+
+    // ---- weight tile of a chunk: verbatim copy of NS*T*4 runs of BCO units from the packed buffer
+    const int total_it = p.Cin8 * T;  // Cin8 holds Cin16 for this kernel
+    const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.wpk);
+    constexpr int WRUNS = NS * T * 4;
+    constexpr int WPT = (WRUNS * BCO + 255) / 256;
+    u32x4* Ws4 = reinterpret_cast<u32x4*>(Ws);
+    const long wblk = (long)blockIdx.y * BCO;
+    u32x4 wstg[WPT];
+    auto wprefetch = [&](int chunk) {
+        const int it0 = chunk * NS * T;
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int e = tid + 256 * j;
+            const int run = e / BCO, col = e % BCO;
+            const int itg = it0 + (run >> 2);
+            const bool ok = (WRUNS * BCO % 256 == 0 || e < WRUNS * BCO) && itg < total_it;
+            const u32x4 v = wp4[((long)(ok ? itg : 0) * 4 + (run & 3)) * p.CoutP + wblk + col];
+            wstg[j] = ok ? v : u32x4{0u, 0u, 0u, 0u};
+        }
+    };
+    auto wcommit = [&]() {
+#pragma unroll
+        for (int j = 0; j < WPT; ++j) {
+            const int e = tid + 256 * j;
+            if (WRUNS * BCO % 256 == 0 || e < WRUNS * BCO) Ws4[e] = wstg[j];
+        }
+    };
+
+    if (p.ep_mode != 0) {
+        for (int c = tid; c < BCO; c += 256) {
+            const int co = blockIdx.y * BCO + c;
+            float e0 = 0.f, e1 = 1.f;
+            if (co < p.Cout) {
+                e0 = p.p0[co];
+                if (p.ep_mode == 1) e1 = expf(p.p1[co]);
+                if (p.ep_mode == 2) e1 = expf(3.f * p.p1[co]);
+            }
+            ep[c] = e0;
+            ep[BCO + c] = e1;
+        }
+    }
+
+    const int nchunks_all = (p.Cin8 * 16 + KC - 1) / KC;
+    const int cps = (nchunks_all + p.ksplit - 1) / p.ksplit;
+    const int chunk0 = blockIdx.z * cps;
+    const int nchunks = chunk0 + cps < nchunks_all ? chunk0 + cps : nchunks_all;
+    if (chunk0 < nchunks) {
+        prefetch(chunk0);
+        wprefetch(chunk0);
+    }
+    const bf16x8* wa = Ws + kk * BCO + wco * (32 * TCO) + l31;  // + ((itl*2 + plane)*2)*BCO + a*32
+    for (int chunk = chunk0; chunk < nchunks; ++chunk) {
+        __syncthreads();
+        commit();
+        wcommit();
+        __syncthreads();
+        if (chunk + 1 < nchunks) {
+            prefetch(chunk + 1);
+            wprefetch(chunk + 1);
+        }
+#pragma unroll
+        for (int s = 0; s < NS; ++s) {
+#pragma unroll
+            for (int tap = 0; tap < T; ++tap) {
+                const int itl = s * T + tap;
+                const int tapoff = (tap / KS) * RW + (tap % KS);
+                bf16x8 ah[TCO], al[TCO], bh[TPX], bl[TPX];
+#pragma unroll
+                for (int a = 0; a < TCO; ++a) {
+                    ah[a] = wa[((itl * 2 + 0) * 2) * BCO + a * 32];
+                    al[a] = wa[((itl * 2 + 1) * 2) * BCO + a * 32];
+                }
+                const bf16x8* bb = Bs + (2 * s + kk) * IMG + tapoff;
+#pragma unroll
+                for (int t = 0; t < TPX; ++t) {
+                    bh[t] = bb[lds_off[t]];
+                    bl[t] = bb[NG * IMG + lds_off[t]];
+                }
+#pragma unroll
+                for (int a = 0; a < TCO; ++a)
+#pragma unroll
+                    for (int t = 0; t < TPX; ++t) {
+                        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[t], acc[a][t], 0, 0, 0);
+                        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[t], acc[a][t], 0, 0, 0);
+                        acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[t], acc[a][t], 0, 0, 0);
+                    }
+            }
+        }
+    }
+
+    __syncthreads();
+    conv_epilogue<TCO, TPX, BCO>(p, acc, ep, co_base, wco, kk, HW, pn, ppix, pvalid);
+}
+
+template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
+static int launch_conv_b3(ConvParams& p, hipStream_t s) {
+    constexpr int BCO = 32 * TCO * WCO, BPX = 32 * TPX * WPX, PAD = KS / 2;
+    tile_geometry(p.H, p.W, BPX, &p.TWp, &p.TH, &p.TF);
+    p.tw_shift = ilog2(p.TWp);
+    p.th_shift = ilog2(p.TH);
+    p.n_wtiles = ceil_div(p.W, p.TWp);
+    p.n_htiles = ceil_div(p.H, p.TH);
+    p.n_ftiles = ceil_div(p.N, p.TF);
+    const int IMG = p.TF * (p.TH + 2 * PAD) * (p.TWp + 2 * PAD);
+    constexpr int NPOS = (KS == 1) ? 1 : (BPX >= 256 ? 4 : (BPX >= 128 ? 2 : 1));
+    constexpr int P2 = (KS == 1 && BPX < 256) ? (BPX >= 64 ? BPX : 64) : 256;
+    if (IMG > P2 * NPOS) {
+        rfn_set_error("conv2d(bf16x3): map %dx%d needs %d LDS slots (> %d supported)", p.H, p.W, IMG, P2 * NPOS);
+        return -7;
+    }
+    size_t lds = (size_t)2 * (KC / 8) * IMG * 16 + (size_t)(KC / 16) * KS * KS * 4 * BCO * 16 + 2 * BCO * 4;
+    auto kern = conv_b3_kernel<KS, WCO, WPX, TCO, TPX, KC>;
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(p.n_wtiles * p.n_htiles * p.n_ftiles, ceil_div(p.Cout, BCO));
+    p.ksplit = 1;
+    const int wgs = grid.x * grid.y;
+    const int nchunks = (p.Cin8 * 16 + KC - 1) / KC;
+    const int HW = p.H * p.W;
+    const bool dense = p.out1_ns == (long)p.cout_split * HW &&
+                       (p.cout_split == p.Cout || p.out2_ns == (long)(p.Cout - p.cout_split) * HW);
+    if (wgs < 128 && nchunks >= 8 && p.ep_mode != 1 && !p.acc1 && !p.acc2 && dense) {
+        int ks_ = 512 / wgs;
+        if (ks_ > nchunks / 2) ks_ = nchunks / 2;
+        if (ks_ > 1) {
+            p.ksplit = ks_;
+            (void)hipMemsetAsync(p.out1, 0, (size_t)p.N * p.cout_split * HW * 4, s);
+            if (p.cout_split != p.Cout) (void)hipMemsetAsync(p.out2, 0, (size_t)p.N * (p.Cout - p.cout_split) * HW * 4, s);
+        }
+    }
+    grid.z = p.ksplit;
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return 0;
+}
+
+extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                                     const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                                     int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
+                                     const float* p0, const float* p1, int act, rfn_stream_t stream) {
+    RFN_CHECK_ARG(in1 && wpk && out1 && C1 > 0 && C2 >= 0 && Cout > 0 && N >= 0 && H > 0 && W > 0, -1);
+    RFN_CHECK_ARG(ks == 1 || ks == 3, -2);
+    RFN_CHECK_ARG(C2 == 0 || in2, -3);
+    RFN_CHECK_ARG(cout_split >= 0 && cout_split <= Cout && (cout_split == Cout || out2), -4);
+    RFN_CHECK_ARG(ep_mode >= 0 && ep_mode <= 3 && (ep_mode == 0 || p0) && ((ep_mode != 1 && ep_mode != 2) || p1), -5);
+    RFN_CHECK_ARG(((uintptr_t)wpk & 15) == 0, -6);
+    if (N == 0) return 0;
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.in1 = in1; p.in2 = in2; p.in1_ns = in1_ns; p.in2_ns = in2_ns; p.C1 = C1; p.C2 = C2;
+    p.wpk = wpk; p.out1 = out1; p.out2 = out2; p.out1_ns = out1_ns; p.out2_ns = out2_ns;
+    p.Cout = Cout; p.cout_split = cout_split; p.acc1 = acc1; p.acc2 = acc2;
+    p.N = N; p.H = H; p.W = W;
+    packed_dims_b3(Cout, C1 + C2, &p.CoutP, &p.Cin8);
+    p.ep_mode = ep_mode; p.act = act; p.p0 = p0; p.p1 = p1;
+    hipStream_t s = (hipStream_t)stream;
+    const bool few_px = (long)N * H * W * ((Cout + 127) / 128) < 256L * 128;
+    int rc;
+    if (ks == 3) {
+        if (Cout <= 32)
+            rc = launch_conv_b3<3, 1, 4, 1, 1, 16>(p, s);   // 32 co x 128 px
+        else if (few_px)
+            rc = launch_conv_b3<3, 2, 2, 1, 1, 16>(p, s);   // 64 co x 64 px
+        else
+            rc = launch_conv_b3<3, 2, 2, 1, 2, 16>(p, s);   // 64 co x 128 px
+    } else {
+        if (Cout <= 32)
+            rc = launch_conv_b3<1, 1, 4, 1, 1, 32>(p, s);
+        else if (few_px || Cout <= 64)
+            rc = launch_conv_b3<1, 2, 2, 1, 1, 32>(p, s);   // 64 co x 64 px
+        else
+            rc = launch_conv_b3<1, 2, 2, 2, 2, 32>(p, s);   // 128 co x 128 px
+    }
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}

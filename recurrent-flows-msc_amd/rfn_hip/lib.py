@@ -29,6 +29,10 @@ SIGNATURES = {
     "rfn_invconv_actnorm_rev_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_i, _c_i, _c_i, _c_s],
     "rfn_conv2d_fwd_f32": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
                            _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
+    "rfn_conv2d_fwd_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
+                              _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
+    "rfn_packed_weight_size_bf16x3": [_c_i, _c_i, _c_i],
+    "rfn_pack_conv_weight_bf16x3": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_packed_weight_size": [_c_i, _c_i, _c_i],
     "rfn_pack_conv_weight_f32": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_conv2d_wgrad_f32": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
@@ -49,7 +53,8 @@ SIGNATURES = {
     "rfn_convlstm_gates_bwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f,
                                    _c_l, _c_i, _c_i, _c_i, _c_s],
 }
-_RESTYPES = {"rfn_last_error": ctypes.c_char_p, "rfn_packed_weight_size": ctypes.c_long}
+_RESTYPES = {"rfn_last_error": ctypes.c_char_p, "rfn_packed_weight_size": ctypes.c_long,
+             "rfn_packed_weight_size_bf16x3": ctypes.c_long}
 
 _lib = None
 

@@ -13,6 +13,12 @@ from . import lib as L
 _i = ctypes.c_int
 _l = ctypes.c_long
 
+import os
+
+# arithmetic of the MFMA convolutions (forward and data-gradient): "bf16x3" = split-precision bf16 MFMA with fp32
+# accumulation (3/16 of the fp32-MFMA cycles, ~1e-5 relative error), "f32" = v_mfma_f32_32x32x2_f32.
+CONV_PRECISION = os.environ.get("RFN_CONV_PRECISION", "bf16x3")
+
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
 CLAMP = {"realnvp": 0, "glow": 1, "softclamp": 2, "none": 3}
 
@@ -106,10 +112,12 @@ def pack_weight(w, flip=False):
     """Pack a torch-layout conv weight [Cout,Cin,k,k] for the MFMA conv kernel (flip=True: data-gradient conv).
     One streaming kernel over the packed buffer; done per call (weights change every optimizer step)."""
     Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-    size = L.load().rfn_packed_weight_size(Cout, Cin, ks)
+    b3 = CONV_PRECISION == "bf16x3"
+    size = (L.load().rfn_packed_weight_size_bf16x3 if b3 else L.load().rfn_packed_weight_size)(Cout, Cin, ks)
     wpk = torch.empty(size, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    L.call("rfn_pack_conv_weight_f32", L.dev(wc, "w"), L.dev(wpk), _i(Cout), _i(Cin), _i(ks), _i(1 if flip else 0))
+    L.call("rfn_pack_conv_weight_bf16x3" if b3 else "rfn_pack_conv_weight_f32", L.dev(wc, "w"), L.dev(wpk), _i(Cout),
+           _i(Cin), _i(ks), _i(1 if flip else 0))
     return wpk
 
 
@@ -126,10 +134,12 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
         out1 = torch.empty((N, cout_split, H, W), device=in1.device, dtype=torch.float32)
     o1p, o1ns = L.frames(out1, "out1")
     o2p, o2ns = (None, 0) if out2 is None else L.frames(out2, "out2")
-    L.call("rfn_conv2d_fwd_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(wpk), o1p, _l(o1ns), o2p,
+    b3 = CONV_PRECISION == "bf16x3"
+    L.call("rfn_conv2d_fwd_bf16x3" if b3 else "rfn_conv2d_fwd_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2),
+           L.dev(wpk), o1p, _l(o1ns), o2p,
            _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W), _i(ks),
            _i(ep_mode), L.dev(p0), L.dev(p1), _i(act),
-           meta=("conv", conv_kernel_name(Cout, ks, N * H * W), 2.0 * N * H * W * (C1 + C2) * Cout * ks * ks,
+           meta=("conv", ("b3:" if b3 else "") + conv_kernel_name(Cout, ks, N * H * W), 2.0 * N * H * W * (C1 + C2) * Cout * ks * ks,
                  "N%d %d+%d->%d %dx%d k%d ep%d%s" % (N, C1, C2, Cout, H, W, ks, ep_mode,
                                                   "" if cout_split == Cout else " split")))
     return out1

@@ -7,6 +7,17 @@ import torch.nn.functional as F
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(params=["bf16x3", "f32"], autouse=True)
+def conv_precision(request):
+    """every test runs with both MFMA arithmetics of the convolutions: the shipped split-precision bf16x3 path and the
+    plain fp32 MFMA path (RFN_CONV_PRECISION)."""
+    from rfn_hip import ops
+    old = ops.CONV_PRECISION
+    ops.CONV_PRECISION = request.param
+    yield request.param
+    ops.CONV_PRECISION = old
+
 from oracle import rfn_oracle as O  # noqa: E402
 
 
@@ -19,6 +30,13 @@ def K():
 
 def cu(t):
     return t.cuda()
+
+
+def ctol():
+    """conv tolerance factor: the split-precision (bf16x3) MFMA path carries ~1e-5 relative error per contraction
+    (2^-16 per product), the fp32 MFMA path ~1e-6; thresholds below are written for fp32 and scaled by this."""
+    from rfn_hip import ops
+    return 5.0 if ops.CONV_PRECISION == "bf16x3" else 1.0
 
 
 def relerr(a, b):
@@ -109,14 +127,14 @@ def test_conv2d_fwd_dgrad_wgrad(K, case):
     gy = torch.randn(ref.shape, generator=g)
     ref.backward(gy)
     out = K.conv2d_raw(cu(x1), cu(x2) if C2 else None, K.pack_weight(cu(w)), Cout, ks)
-    assert relerr(out, ref) < 2e-5, "forward"
+    assert relerr(out, ref) < 2e-5 * ctol(), "forward"
     # data gradient through the same kernel with flipped/transposed packing, split into the two sources
     g1 = torch.empty(N, C1, H, W, device="cuda")
     g2 = torch.empty(N, C2, H, W, device="cuda") if C2 else None
     K.conv2d_raw(cu(gy), None, K.pack_weight(cu(w), True), Cin, ks, out1=g1, out2=g2, cout_split=C1)
-    assert relerr(g1, xin.grad[:, :C1]) < 2e-5, "dgrad in1"
+    assert relerr(g1, xin.grad[:, :C1]) < 2e-5 * ctol(), "dgrad in1"
     if C2:
-        assert relerr(g2, xin.grad[:, C1:]) < 2e-5, "dgrad in2"
+        assert relerr(g2, xin.grad[:, C1:]) < 2e-5 * ctol(), "dgrad in2"
     gw = K.conv2d_wgrad(cu(x1), cu(x2) if C2 else None, cu(gy), Cout, ks)
     assert relerr(gw, wr.grad) < 1e-4, "wgrad"
 
@@ -145,9 +163,9 @@ def test_conv_epilogues_fwd_bwd(K, ep_mode, act):
     p0k = cu(p0.detach()).requires_grad_(True)
     p1k = cu(p1.detach()).requires_grad_(True) if ep_mode != 3 else None
     out = K.conv_ep(xk, None, wk, p0k, p1k, ep_mode, act)
-    assert relerr(out, ref) < 2e-5
+    assert relerr(out, ref) < 2e-5 * ctol()
     out.backward(cu(gy))
-    assert relerr(xk.grad, xr.grad) < 5e-5
+    assert relerr(xk.grad, xr.grad) < 5e-5 * ctol()
     assert relerr(wk.grad, w.grad) < 1e-4
     assert relerr(p0k.grad, p0.grad) < 1e-4
     if ep_mode != 3:
@@ -210,6 +228,6 @@ def test_tap_expanded_zeros_conv_fwd_wgrad(K, N, Cin, C, H, W):
     gpre = torch.randn(N, C, H, W, generator=g)
     F.conv2d(x, w, None, padding=1).backward(gpre)
     o = K.zeros_conv_fwd(cu(x), cu(w.detach()), cu(b), cu(l))
-    assert relerr(o, ref) < 2e-5
+    assert relerr(o, ref) < 2e-5 * ctol()
     gw = K.zeros_conv_wgrad(cu(x), cu(gpre), C, 3)
     assert relerr(gw, w.grad) < 1e-4
