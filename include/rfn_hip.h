@@ -82,6 +82,16 @@ long rfn_packed_weight_size_bf16x3(int Cout, int Cin, int ks); /* in floats (4-b
 int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
                                 rfn_stream_t stream);
 
+/* Split-precision weight-gradient GEMM: gw[M][Nc] += Σ_{f,p} a[f][m][p] * b[f][n][p]  (a: [F,M,HW] frame stride a_ns,
+ * b: [F,Nc,HW] frame stride b_ns; HW % 4 == 0, 16-byte aligned bases).  gw is accumulated with float atomics (caller
+ * zeroes it).  1x1 weight gradients use it directly (a = output grad, b = conv input); 3x3 ones first expand the
+ * smaller operand: b = rfn_im2col3x3_f32(input) [9*Cin rows, tap-major] or a = rfn_tap_scatter_f32(grad) [9*Cout rows]. */
+int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw, int F, int HW,
+                          rfn_stream_t stream);
+/* out[n][tap*Cin+ci][y][x] = in[n][ci][y+dy-1][x+dx-1] (0 outside); two-source input; out dense [N,9*Cin,H,W]. */
+int rfn_im2col3x3_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2, float* out, int N,
+                      int H, int W, rfn_stream_t stream);
+
 /* number of floats of a packed weight buffer for (Cout, Cin, ks) */
 long rfn_packed_weight_size(int Cout, int Cin, int ks);
 /* Pack torch-layout weights w[Cout][Cin][ks][ks] for rfn_conv2d_fwd_f32.

@@ -1,0 +1,222 @@
+// Weight gradients as one split-precision GEMM:  gw[m][n] += Σ_{frames, pixels} A[f][m][p] * B[f][n][p].
+//
+// Every weight gradient of the path is brought to this 1x1 form by expanding the SMALL operand in HBM:
+//   * 1x1 conv:                 A = grad [M = Cout],       B = input [N = Cin]
+//   * 3x3 conv, Cin <= Cout:    A = grad,                  B = im2col3x3(input) [N = 9*Cin]   (rfn_im2col3x3_f32)
+//   * 3x3 conv, Cout <  Cin:    A = tap_scatter(grad) [M = 9*Cout] (rfn_tap_scatter_f32),     B = input
+// so the shifted-window reads of a 3x3 weight gradient never reach this kernel and the 8 consecutive k (pixels) an
+// MFMA operand lane needs are 8 consecutive fp32 of one channel plane in NCHW: staged with 16-byte loads, split into
+// bf16 hi/lo (see conv_bf16x3.hip) and stored as [row][k-group] 16-byte units with an odd row stride, so both fragment
+// reads are conflict-free ds_read_b128.  K (all pixels of all frames) is split over gridDim.x; a workgroup sweeps its
+// stages with register prefetch and emits float atomics once.
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct GemmWgradParams {
+    const float* a;
+    const float* b;
+    long a_ns, b_ns;
+    int M, N;
+    float* gw;  // [M][N]
+    int F, HW;  // frames, pixels per frame (HW % 4 == 0)
+    long total; // F*HW
+    int n_stages;
+};
+
+template <int WM, int WN, int TM, int TN, int KP>
+__global__ __launch_bounds__(256) void gemm_wgrad_b3_kernel(const GemmWgradParams p) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int NU = KP / 8;        // 16-byte units (8 pixels) per row and stage
+    constexpr int RS = NU + 1;        // odd-ish row stride in units -> conflict-free b128 fragment reads
+    constexpr int AU = BM * NU / 256; // units staged per thread (A), BM*NU is a multiple of 256
+    constexpr int BU = BN * NU / 256;
+    static_assert(WM * WN == 4 && (BM * NU) % 256 == 0 && (BN * NU) % 256 == 0, "tile/stage shape");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bf16x8* Ah = reinterpret_cast<bf16x8*>(lds_raw);
+    bf16x8* Al = Ah + BM * RS;
+    bf16x8* Bh = Al + BM * RS;
+    bf16x8* Bl = Bh + BN * RS;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int m0 = blockIdx.z * BM, n0 = blockIdx.y * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // staging: unit e = tid + 256*u  ->  row = e / NU, k-group = e % NU   (consecutive threads = consecutive pixels)
+    float4 ast[AU][2], bst[BU][2];
+    auto load8 = [&](const float* base, long ns, int rows, int row, long q0, float4 (&dst)[2]) {
+        // two 4-pixel groups; a group never straddles a frame because HW % 4 == 0
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const long q = q0 + 4 * h;
+            const bool ok = row < rows && q < p.total;
+            const long qq = ok ? q : 0;
+            const long f = qq / p.HW;
+            const int px = (int)(qq - f * p.HW);
+            const float4 v = *reinterpret_cast<const float4*>(base + f * ns + (long)(ok ? row : 0) * p.HW + px);
+            dst[h] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+        }
+    };
+    auto prefetch = [&](int stage) {
+        const long qs = (long)stage * KP;
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int e = tid + 256 * u;
+            load8(p.a, p.a_ns, p.M, m0 + e / NU, qs + 8 * (e % NU), ast[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            const int e = tid + 256 * u;
+            load8(p.b, p.b_ns, p.N, n0 + e / NU, qs + 8 * (e % NU), bst[u]);
+        }
+    };
+    auto split_store = [&](const float4 (&src)[2], bf16x8* hi_p, bf16x8* lo_p) {
+        const float v[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const __bf16 h = (__bf16)v[c];
+            hi[c] = h;
+            lo[c] = (__bf16)(v[c] - (float)h);
+        }
+        *hi_p = hi;
+        *lo_p = lo;
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int u = 0; u < AU; ++u) {
+            const int e = tid + 256 * u;
+            const int o = (e / NU) * RS + e % NU;
+            split_store(ast[u], Ah + o, Al + o);
+        }
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            const int e = tid + 256 * u;
+            const int o = (e / NU) * RS + e % NU;
+            split_store(bst[u], Bh + o, Bl + o);
+        }
+    };
+
+    const int arow = (wm * TM * 32 + l31) * RS + kk;  // + i*32*RS + 2*s
+    const int brow = (wn * TN * 32 + l31) * RS + kk;
+    int stage = blockIdx.x;
+    if (stage < p.n_stages) prefetch(stage);
+    for (; stage < p.n_stages; stage += gridDim.x) {
+        __syncthreads();
+        commit();
+        __syncthreads();
+        if (stage + (int)gridDim.x < p.n_stages) prefetch(stage + gridDim.x);
+#pragma unroll
+        for (int s = 0; s < KP / 16; ++s) {
+            bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                ah[i] = Ah[arow + i * 32 * RS + 2 * s];
+                al[i] = Al[arow + i * 32 * RS + 2 * s];
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = Bh[brow + j * 32 * RS + 2 * s];
+                bl[j] = Bl[brow + j * 32 * RS + 2 * s];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[i], bh[j], acc[i][j], 0, 0, 0);
+                }
+        }
+    }
+    // D[i = m][j = n]: col = lane&31 = n (32 consecutive floats of a gw row = one 128-byte atomic segment)
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (m < p.M && n < p.N) atomicAdd(&p.gw[(long)m * p.N + n], acc[i][j][r]);
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN, int KP>
+static void launch_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    p.n_stages = (int)((p.total + KP - 1) / KP);
+    size_t lds = (size_t)2 * (BM + BN) * (KP / 8 + 1) * 16;
+    int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    int S = 1024 / tiles;
+    if (S < 1) S = 1;
+    if (S > p.n_stages) S = p.n_stages;
+    auto kern = gemm_wgrad_b3_kernel<WM, WN, TM, TN, KP>;
+    if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
+    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+}
+
+extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw,
+                                     int F, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(a && b && gw && M > 0 && Nc > 0 && F >= 0 && HW > 0, -1);
+    RFN_CHECK_ARG(HW % 4 == 0 && a_ns % 4 == 0 && b_ns % 4 == 0, -2);
+    RFN_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0, -3);
+    if (F == 0) return 0;
+    GemmWgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = a; p.b = b; p.a_ns = a_ns; p.b_ns = b_ns; p.M = M; p.N = Nc; p.gw = gw; p.F = F; p.HW = HW;
+    p.total = (long)F * HW;
+    hipStream_t s = (hipStream_t)stream;
+    if (M <= 64)
+        launch_gemm_wgrad<1, 4, 2, 2, 32>(p, s);   // 64 x 256
+    else if (Nc <= 64)
+        launch_gemm_wgrad<4, 1, 2, 2, 32>(p, s);   // 256 x 64
+    else
+        launch_gemm_wgrad<2, 2, 2, 2, 64>(p, s);   // 128 x 128
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ im2col (3x3, pad 1)
+// X9[n][tap*Cin + ci][y][x] = in[n][ci][y+dy-1][x+dx-1] (0 outside), two-source input like the convolutions.
+__global__ void im2col3x3_kernel(const float* __restrict__ in1, long in1_ns, int C1, const float* __restrict__ in2,
+                                 long in2_ns, int C2, float* __restrict__ out, int N, int H, int W) {
+    const int Cin = C1 + C2;
+    const long HW = (long)H * W, total = (long)N * 9 * Cin * HW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int x = (int)(idx % W);
+        long r = idx / W;
+        const int y = (int)(r % H);
+        r /= H;
+        const int tc = (int)(r % (9 * Cin));
+        const long n = r / (9 * Cin);
+        const int t = tc / Cin, ci = tc - t * Cin;
+        const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+        float v = 0.f;
+        if (yy >= 0 && yy < H && xx >= 0 && xx < W)
+            v = ci < C1 ? in1[n * in1_ns + (long)ci * HW + (long)yy * W + xx]
+                        : in2[n * in2_ns + (long)(ci - C1) * HW + (long)yy * W + xx];
+        out[idx] = v;
+    }
+}
+extern "C" int rfn_im2col3x3_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                                 float* out, int N, int H, int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(in1 && out && C1 > 0 && C2 >= 0 && (C2 == 0 || in2) && N >= 0 && H > 0 && W > 0, -1);
+    if (N == 0) return 0;
+    long tot = (long)N * 9 * (C1 + C2) * H * W;
+    int grid = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in1, in1_ns, C1, in2, in2_ns, C2,
+                       out, N, H, W);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}

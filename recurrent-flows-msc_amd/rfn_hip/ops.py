@@ -163,11 +163,47 @@ def wgrad_kernel_name(Cout, Cin, ks, HW):
     return "wgrad_mfma_kernel<%d,%s,64>" % (ks, cfg)
 
 
+def gemm_wgrad(a, b, M, Nc, arena=None):
+    """gw[M][Nc] = Σ_{frames,pixels} a[f,m,p] b[f,n,p] on the split-precision MFMA GEMM (rfn_gemm_wgrad_bf16x3)."""
+    F_, HW = int(a.shape[0]), _hw(a)
+    ap, ans = L.frames(a, "a")
+    bp, bns = L.frames(b, "b")
+    gw = _zeros(arena, M, Nc, device=a.device)
+    L.call("rfn_gemm_wgrad_bf16x3", ap, _l(ans), _i(M), bp, _l(bns), _i(Nc), L.dev(gw), _i(F_), _i(HW),
+           meta=("wgrad", "b3:gemm_wgrad_b3_kernel", 2.0 * F_ * HW * M * Nc, "F%d %dx%d HW%d" % (F_, M, Nc, HW)))
+    return gw
+
+
+def conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena=None):
+    """weight gradient through the split-precision GEMM: 3x3 convs expand their smaller operand in HBM first
+    (im2col of the input when Cin <= Cout, tap-scatter of the gradient otherwise)."""
+    N, C1, H, W = in1.shape
+    C2 = 0 if in2 is None else int(in2.shape[1])
+    Cin = C1 + C2
+    if ks == 1:
+        x = in1 if in2 is None else torch.cat((in1, in2), 1)
+        return gemm_wgrad(g, x, Cout, Cin, arena).view(Cout, Cin, 1, 1)
+    if Cin <= Cout:
+        i1p, i1ns = L.frames(in1, "in1")
+        i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
+        x9 = torch.empty((N, 9 * Cin, H, W), device=in1.device, dtype=torch.float32)
+        L.call("rfn_im2col3x3_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(x9), _i(N), _i(H), _i(W))
+        gw = gemm_wgrad(g, x9, Cout, 9 * Cin, arena)  # [co][tap*Cin + ci]
+        return gw.view(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
+    x = in1 if in2 is None else torch.cat((in1, in2), 1)
+    gs = torch.empty((N, 9 * Cout, H, W), device=in1.device, dtype=torch.float32)
+    L.call("rfn_tap_scatter_f32", L.dev(g.contiguous()), L.dev(gs), _i(N), _i(Cout), _i(H), _i(W))
+    gw = gemm_wgrad(gs, x, 9 * Cout, Cin, arena)  # [tap*Cout + co][ci]
+    return gw.view(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
+
+
 def conv2d_wgrad(in1, in2, g, Cout, ks, arena=None):
     """returns gw [Cout, Cin, ks, ks]"""
     N, C1, H, W = in1.shape
     C2 = 0 if in2 is None else int(in2.shape[1])
     Cin = C1 + C2
+    if CONV_PRECISION == "bf16x3" and (H * W) % 4 == 0:
+        return conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena)
     i1p, i1ns = L.frames(in1, "in1")
     i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
     gp, gns = L.frames(g, "g")
@@ -201,7 +237,7 @@ def zeros_conv_fwd(x, w, b, logs):
 
 def zeros_conv_wgrad(x, g_pre, C, ks, arena=None):
     """weight gradient of the conv inside Conv2dZeros given g_pre = grad wrt (conv + b); same switch as the forward."""
-    if ks != 3 or C > TAP_MAX_COUT:
+    if ks != 3 or C > TAP_MAX_COUT or (CONV_PRECISION == "bf16x3" and _hw(x) % 4 == 0):
         return conv2d_wgrad(x, None, g_pre, C, ks, arena)
     N, Cin, H, W = x.shape
     Gs = torch.empty((N, 9 * C, H, W), device=x.device, dtype=torch.float32)
