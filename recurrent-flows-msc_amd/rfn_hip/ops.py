@@ -139,10 +139,22 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
            L.dev(wpk), o1p, _l(o1ns), o2p,
            _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W), _i(ks),
            _i(ep_mode), L.dev(p0), L.dev(p1), _i(act),
-           meta=("conv", ("b3:" if b3 else "") + conv_kernel_name(Cout, ks, N * H * W), 2.0 * N * H * W * (C1 + C2) * Cout * ks * ks,
+           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W) if b3 else conv_kernel_name(Cout, ks, N * H * W),
+                 2.0 * N * H * W * (C1 + C2) * Cout * ks * ks,
                  "N%d %d+%d->%d %dx%d k%d ep%d%s" % (N, C1, C2, Cout, H, W, ks, ep_mode,
-                                                  "" if cout_split == Cout else " split")))
+                                                  "" if cout_split == Cout else " split"),
+                 4.0 * (N * H * W * (C1 + C2 + Cout) + (C1 + C2) * Cout * ks * ks)))
     return out1
+
+
+def conv_b3_kernel_name(Cout, ks, npix=1 << 30):
+    """the template instantiation rfn_conv2d_fwd_bf16x3 dispatches to (mirrors csrc/conv_bf16x3.hip)"""
+    few = npix * ((Cout + 127) // 128) < 256 * 128
+    if ks == 3:
+        cfg = "1,4,1,1" if Cout <= 32 else ("2,2,1,1" if few else "2,2,1,2")
+        return "conv_b3_kernel<3,%s,16>" % cfg
+    cfg = "1,4,1,1" if Cout <= 32 else ("2,2,1,1" if (few or Cout <= 64) else "2,2,2,2")
+    return "conv_b3_kernel<1,%s,32>" % cfg
 
 
 def conv_kernel_name(Cout, ks, npix=1 << 30):
@@ -170,7 +182,9 @@ def gemm_wgrad(a, b, M, Nc, arena=None):
     bp, bns = L.frames(b, "b")
     gw = _zeros(arena, M, Nc, device=a.device)
     L.call("rfn_gemm_wgrad_bf16x3", ap, _l(ans), _i(M), bp, _l(bns), _i(Nc), L.dev(gw), _i(F_), _i(HW),
-           meta=("wgrad", "b3:gemm_wgrad_b3_kernel", 2.0 * F_ * HW * M * Nc, "F%d %dx%d HW%d" % (F_, M, Nc, HW)))
+           meta=("wgrad", "gemm_wgrad_b3_kernel<%s>" % ("1,4,2,2,32" if M <= 64 else ("4,1,2,2,32" if Nc <= 64 else
+                                                                                        "2,2,2,2,64")),
+                 2.0 * F_ * HW * M * Nc, "F%d %dx%d HW%d" % (F_, M, Nc, HW), 4.0 * (F_ * HW * (M + Nc) + M * Nc)))
     return gw
 
 
@@ -211,7 +225,7 @@ def conv2d_wgrad(in1, in2, g, Cout, ks, arena=None):
     L.call("rfn_conv2d_wgrad_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), gp, _l(gns), _i(Cout), L.dev(gwt),
            _i(N), _i(H), _i(W), _i(ks),
            meta=("wgrad", wgrad_kernel_name(Cout, Cin, ks, H * W), 2.0 * N * H * W * Cin * Cout * ks * ks,
-                 "N%d %d->%d %dx%d k%d" % (N, Cin, Cout, H, W, ks)))
+                 "N%d %d->%d %dx%d k%d" % (N, Cin, Cout, H, W, ks), 4.0 * (N * H * W * (Cin + Cout) + Cin * Cout * ks * ks)))
     if ks == 1:
         return gwt.view(Cout, Cin, 1, 1)  # tap-major == torch layout when there is a single tap
     gw = torch.empty((Cout, Cin, ks, ks), device=in1.device, dtype=torch.float32)
