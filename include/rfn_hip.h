@@ -82,6 +82,17 @@ long rfn_packed_weight_size_bf16x3(int Cout, int Cin, int ks); /* in floats (4-b
 int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
                                 rfn_stream_t stream);
 
+/* Pack MANY weights in one launch (a whole flow: ~300 descriptors per training step instead of ~370 launches).
+ * descs_device: device array of n rfn_pack_desc; mode 0 forward, 1 data-gradient (transposed, taps mirrored),
+ * 2 tap-expanded 1x1 form of a 3x3 conv with tiny Cout (w'[tap*Cout+co][ci] = w[co][ci][tap]).  Each wpk must hold
+ * rfn_packed_weight_size_bf16x3 floats of the LOGICAL conv (mode 2: Cout' = 9*Cout, ks' = 1). */
+typedef struct {
+    const float* w;
+    float* wpk;
+    int Cout, Cin, ks, mode;
+} rfn_pack_desc;
+int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_stream_t stream);
+
 /* Split-precision weight-gradient GEMM: gw[M][Nc] += Σ_{f,p} a[f][m][p] * b[f][n][p]  (a: [F,M,HW] frame stride a_ns,
  * b: [F,Nc,HW] frame stride b_ns; HW % 4 == 0, 16-byte aligned bases).  gw is accumulated with float atomics (caller
  * zeroes it).  1x1 weight gradients use it directly (a = output grad, b = conv input); 3x3 ones first expand the

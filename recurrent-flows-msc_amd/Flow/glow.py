@@ -44,7 +44,7 @@ class GlowStep(nn.Module):
             ld = torch.slogdet(self.invconv.weight)[1]
         return (ld + torch.sum(self.norm.logs)) * hw
 
-    def forward(self, x, condition, logdet, reverse, Wm=None, defer_logdet=None):
+    def forward(self, x, condition, logdet, reverse, Wm=None, defer_logdet=None, packs=None):
         """`Wm` (optional): this step's C×C matrix when the caller built all matrices of a level in one batched
         computation; `defer_logdet` (optional list): receives the data dependent log-det [N] instead of adding it (the
         caller sums all steps at once and adds the parameter-only terms per level)."""
@@ -71,7 +71,7 @@ class GlowStep(nn.Module):
                     z = K.actnorm_invconv_fwd(x.detach(), an.bias.detach().reshape(-1), an.logs.detach().reshape(-1),
                                               Wm.detach())
                     aff.maybe_init(z[:, : z.shape[1] // 2], condition)
-            out, dl = K.GlowStepFn.apply(x, condition, Wm, an.bias, an.logs, *aff.nn_params(), act, clamp)
+            out, dl = K.GlowStepFn.apply(x, condition, Wm, an.bias, an.logs, *aff.nn_params(), act, clamp, packs)
             if defer_logdet is not None:
                 defer_logdet.append(dl)
             elif logdet is not None:
@@ -159,16 +159,38 @@ class ListGlow(nn.Module):
         W = torch.matmul(p, torch.matmul(L, U))
         return W, log_s.sum() * hw
 
+    def _packed_weights(self):
+        """one launch re-packs (and hi/lo splits) every coupling-net weight of the flow, forward and data-gradient
+        orientation; returns {GlowStep: (w1 f, w1 d, w2 f, w2 d, w3 f, w3 d)} or None (fp32 arithmetic / CPU)."""
+        if K.CONV_PRECISION != "bf16x3":
+            return None
+        steps = [s for _, ss, _ in self._level_steps() for s in ss]
+        items = []
+        for s in steps:
+            n0, n2, n4 = s.affine.net[0], s.affine.net[2], s.affine.net[4]
+            w3 = n4.conv.weight
+            items += [(n0.conv.weight, 0), (n0.conv.weight, 1), (n2.conv.weight, 0), (n2.conv.weight, 1),
+                      (w3, 2 if K.zeros_conv_uses_taps(w3) else 0), (w3, 1)]
+        if not items or not items[0][0].is_cuda:
+            return None
+        plan = getattr(self, "_pack_plan", None)
+        if plan is None or not plan.valid_for(items):
+            plan = self._pack_plan = K.PackPlan(items)
+        plan.run()
+        return {s: tuple(plan.bufs[6 * i:6 * i + 6]) for i, s in enumerate(steps)}
+
     def f(self, x, condition, logdet):
         """Flow/glow.py:105-117 (same order of operations; per-level batching of the tiny parameter algebra)."""
         z = x
         dls, const = [], 0
+        packs = self._packed_weights()
         for l, (squeeze, steps, split) in enumerate(self._level_steps()):
             z = squeeze(z, undo_squeeze=False)
             W, c = self._batched_invconv(steps, z.shape[2] * z.shape[3])
             for k, step in enumerate(steps):
                 if W is not None:
-                    z, _ = step(z, condition[l], logdet=logdet, reverse=False, Wm=W[k], defer_logdet=dls)
+                    z, _ = step(z, condition[l], logdet=logdet, reverse=False, Wm=W[k], defer_logdet=dls,
+                                packs=None if packs is None else packs[step])
                 else:
                     z, logdet = step(z, condition[l], logdet=logdet, reverse=False)
             if W is not None:

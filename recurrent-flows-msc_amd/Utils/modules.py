@@ -60,24 +60,27 @@ def per_step_batchnorm(bn, x, steps):
         return bn(x)
     SB, C, H, W = x.shape
     B = SB // steps
-    xv = x.view(steps, B, C, H, W)
-    mean = xv.mean(dim=(1, 3, 4), keepdim=True)
-    var = xv.var(dim=(1, 3, 4), unbiased=False, keepdim=True)
-    y = (xv - mean) * torch.rsqrt(var + bn.eps)
-    if bn.affine:
-        y = y * bn.weight.view(1, 1, C, 1, 1) + bn.bias.view(1, 1, C, 1, 1)
-    if bn.track_running_stats and bn.training:
+    # steps become channel groups: [S*B,C,H,W] -> [B, S*C, H, W]; one fused batch-norm launch then normalises every
+    # (step, channel) pair over its own (B,H,W) samples.  Temporary running buffers with momentum 1 receive the batch
+    # mean / unbiased variance of each pair for the EMA below.
+    xt = x.view(steps, B, C, H, W).transpose(0, 1).reshape(B, steps * C, H, W)
+    track = bn.track_running_stats and bn.training
+    tmp_m = torch.zeros(steps * C, device=x.device, dtype=x.dtype) if track else None
+    tmp_v = torch.ones(steps * C, device=x.device, dtype=x.dtype) if track else None
+    w = bn.weight.repeat(steps) if bn.affine else None
+    b = bn.bias.repeat(steps) if bn.affine else None
+    yt = torch.nn.functional.batch_norm(xt, tmp_m, tmp_v, w, b, True, 1.0, bn.eps)
+    y = yt.view(B, steps, C, H, W).transpose(0, 1).reshape(SB, C, H, W)
+    if track:
         with torch.no_grad():
-            n = B * H * W
             m = bn.momentum if bn.momentum is not None else 0.1
             # r <- (1-m) r + m s_t for t = 0..steps-1  ==  (1-m)^S r + Σ_t m (1-m)^(S-1-t) s_t
             coef = m * (1.0 - m) ** torch.arange(steps - 1, -1, -1, device=x.device, dtype=x.dtype)
             decay = (1.0 - m) ** steps
-            bn.running_mean.mul_(decay).add_((coef.view(steps, 1) * mean.detach().view(steps, C)).sum(0))
-            unb = var.detach().view(steps, C) * (n / max(n - 1, 1))
-            bn.running_var.mul_(decay).add_((coef.view(steps, 1) * unb).sum(0))
+            bn.running_mean.mul_(decay).add_((coef.view(steps, 1) * tmp_m.view(steps, C)).sum(0))
+            bn.running_var.mul_(decay).add_((coef.view(steps, 1) * tmp_v.view(steps, C)).sum(0))
             bn.num_batches_tracked += steps
-    return y.view(SB, C, H, W)
+    return y
 
 
 def run_time_batched(seq, x, steps):

@@ -18,7 +18,7 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 static inline void packed_dims_b3(int Cout_l, int Cin_l, int* CoutP, int* Cin16) {
-    *CoutP = ((Cout_l + 127) / 128) * 128;
+    *CoutP = ((Cout_l + 255) / 256) * 256;
     *Cin16 = (Cin_l + 15) / 16;
 }
 
@@ -75,6 +75,62 @@ extern "C" int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout,
     int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_weight_b3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
                        reinterpret_cast<bf16x8*>(wpk), Cout, Cin, ks, CoutP, Cin16, transpose_flip);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- all weights of a model in ONE launch: descriptor table in device memory, blockIdx.y = descriptor.
+// mode 0: forward conv, 1: data-gradient conv (transposed + mirrored taps), 2: tap-expanded 1x1 form of a 3x3 conv with
+// tiny Cout (logical weight w'[tap*Cout + co][ci] = w[co][ci][tap], see rfn_tap_gather_f32).
+struct PackDesc {  // mirrors rfn_pack_desc in include/rfn_hip.h
+    const float* w;
+    float* wpk;
+    int Cout, Cin, ks, mode;
+};
+__global__ void pack_weights_batched_b3_kernel(const PackDesc* __restrict__ descs) {
+    const PackDesc d = descs[blockIdx.y];
+    const int T_src = d.ks * d.ks;
+    int Co_l, Ci_l, T;
+    if (d.mode == 0) { Co_l = d.Cout; Ci_l = d.Cin; T = T_src; }
+    else if (d.mode == 1) { Co_l = d.Cin; Ci_l = d.Cout; T = T_src; }
+    else { Co_l = T_src * d.Cout; Ci_l = d.Cin; T = 1; }
+    const int CoutP = ((Co_l + 255) / 256) * 256, Cin16 = (Ci_l + 15) / 16;
+    bf16x8* wpk = reinterpret_cast<bf16x8*>(d.wpk);
+    const long total = (long)Cin16 * T * 2 * CoutP;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int co = (int)(idx % CoutP);
+        long r = idx / CoutP;
+        const int g = (int)(r & 1);
+        r >>= 1;
+        const int tap = (int)(r % T);
+        const int c16 = (int)(r / T);
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int ci = c16 * 16 + g * 8 + j;
+            float v = 0.f;
+            if (co < Co_l && ci < Ci_l) {
+                if (d.mode == 0)
+                    v = d.w[((long)co * d.Cin + ci) * T_src + tap];
+                else if (d.mode == 1)
+                    v = d.w[((long)ci * d.Cin + co) * T_src + (T_src - 1 - tap)];
+                else
+                    v = d.w[((long)(co % d.Cout) * d.Cin + ci) * T_src + co / d.Cout];
+            }
+            const __bf16 h = (__bf16)v;
+            hi[j] = h;
+            lo[j] = (__bf16)(v - (float)h);
+        }
+        const long base = ((long)(c16 * T + tap) * 2) * 2 * CoutP;
+        wpk[base + (long)(0 * 2 + g) * CoutP + co] = hi;
+        wpk[base + (long)(1 * 2 + g) * CoutP + co] = lo;
+    }
+}
+extern "C" int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_stream_t stream) {
+    RFN_CHECK_ARG(descs_device && n >= 0, -1);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(pack_weights_batched_b3_kernel, dim3(24, n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const PackDesc*>(descs_device));
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -367,8 +423,10 @@ extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, cons
             rc = launch_conv_b3<1, 1, 4, 1, 1, 32>(p, s);
         else if (few_px || Cout <= 64)
             rc = launch_conv_b3<1, 2, 2, 1, 1, 32>(p, s);   // 64 co x 64 px
-        else
+        else if (Cout <= 128)
             rc = launch_conv_b3<1, 2, 2, 2, 2, 32>(p, s);   // 128 co x 128 px
+        else
+            rc = launch_conv_b3<1, 4, 1, 2, 2, 32>(p, s);   // 256 co x 64 px: the input tile is read once for 256 couts
     }
     if (rc) return rc;
     RFN_LAUNCH_CHECK();

@@ -121,6 +121,35 @@ def pack_weight(w, flip=False):
     return wpk
 
 
+class PackPlan:
+    """Persistent packed-weight buffers for a list of (weight, mode) and ONE launch that refreshes all of them
+    (rfn_pack_conv_weights_batched_bf16x3).  mode: 0 forward, 1 data-gradient, 2 tap-expanded 1x1 (tiny-Cout 3x3)."""
+
+    def __init__(self, items):
+        import numpy as np
+        self.items = list(items)
+        self.ptrs = [w.data_ptr() for w, _ in self.items]
+        dev = self.items[0][0].device
+        lib = L.load()
+        self.bufs = []
+        rec = np.zeros(len(self.items), dtype=np.dtype([("w", "<u8"), ("wpk", "<u8"), ("Cout", "<i4"), ("Cin", "<i4"),
+                                                          ("ks", "<i4"), ("mode", "<i4")]))
+        for i, (w, mode) in enumerate(self.items):
+            Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
+            assert w.is_contiguous() and w.dtype == torch.float32
+            lc, lk = (9 * Cout, 1) if mode == 2 else (Cout, ks)
+            buf = torch.empty(lib.rfn_packed_weight_size_bf16x3(lc, Cin, lk), device=dev, dtype=torch.float32)
+            self.bufs.append(buf)
+            rec[i] = (w.data_ptr(), buf.data_ptr(), Cout, Cin, ks, mode)
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+
+    def valid_for(self, items):
+        return len(items) == len(self.items) and all(w.data_ptr() == p for (w, _), p in zip(items, self.ptrs))
+
+    def run(self):
+        L.call("rfn_pack_conv_weights_batched_bf16x3", L._c_f(self.table.data_ptr()), _i(len(self.items)))
+
+
 def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1=None, out2=None, cout_split=None,
                acc1=False, acc2=False):
     """out = epilogue(conv(cat(in1,in2))) ; see rfn_conv2d_fwd_f32."""
@@ -153,7 +182,7 @@ def conv_b3_kernel_name(Cout, ks, npix=1 << 30):
     if ks == 3:
         cfg = "1,4,1,1" if Cout <= 32 else ("2,2,1,1" if few else "2,2,1,2")
         return "conv_b3_kernel<3,%s,16>" % cfg
-    cfg = "1,4,1,1" if Cout <= 32 else ("2,2,1,1" if (few or Cout <= 64) else "2,2,2,2")
+    cfg = "1,4,1,1" if Cout <= 32 else ("2,2,1,1" if (few or Cout <= 64) else ("2,2,2,2" if Cout <= 128 else "4,1,2,2"))
     return "conv_b3_kernel<1,%s,32>" % cfg
 
 
@@ -236,14 +265,20 @@ def conv2d_wgrad(in1, in2, g, Cout, ks, arena=None):
 TAP_MAX_COUT = 8  # 3x3 convs with at most this many outputs run tap-expanded (1x1 to 9*C channels + shift-add)
 
 
-def zeros_conv_fwd(x, w, b, logs):
-    """Conv2dZeros forward (glow_modules.py:119-121): (conv3x3(x) + b) * exp(3 logs).  Tiny Cout -> tap-expanded."""
+def zeros_conv_uses_taps(w):
+    return int(w.shape[2]) == 3 and int(w.shape[0]) <= TAP_MAX_COUT
+
+
+def zeros_conv_fwd(x, w, b, logs, wpk=None):
+    """Conv2dZeros forward (glow_modules.py:119-121): (conv3x3(x) + b) * exp(3 logs).  Tiny Cout -> tap-expanded.
+    `wpk` (optional): pre-packed weight (mode 2 = tap-expanded when zeros_conv_uses_taps(w), else mode 0)."""
     C, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-    if ks != 3 or C > TAP_MAX_COUT:
-        return conv2d_raw(x, None, pack_weight(w), C, ks, 2, b, logs, 0)
+    if not zeros_conv_uses_taps(w):
+        return conv2d_raw(x, None, wpk if wpk is not None else pack_weight(w), C, ks, 2, b, logs, 0)
     N, _, H, W = x.shape
-    wt = w.detach().permute(2, 3, 0, 1).reshape(9 * C, Cin, 1, 1).contiguous()  # [tap*C + co][ci]
-    P = conv2d_raw(x, None, pack_weight(wt), 9 * C, 1)
+    if wpk is None:
+        wpk = pack_weight(w.detach().permute(2, 3, 0, 1).reshape(9 * C, Cin, 1, 1).contiguous())  # [tap*C + co][ci]
+    P = conv2d_raw(x, None, wpk, 9 * C, 1)
     o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
     L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b), L.dev(logs), L.dev(o), _i(N), _i(C), _i(H), _i(W))
     return o
@@ -374,7 +409,9 @@ class GlowStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cond, Wm, an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift,
-                act, clamp_type):
+                act, clamp_type, packs=None):
+        """`packs` (optional): (w1 fwd, w1 dgrad, w2 fwd, w2 dgrad, w3 fwd, w3 dgrad) packed buffers kept fresh by the
+        caller's PackPlan; without it each weight is packed on the fly."""
         N, C, H, W = x.shape
         Ch = C // 2
         Hd = int(w1.shape[0])
@@ -382,9 +419,13 @@ class GlowStepFn(torch.autograd.Function):
         out = actnorm_invconv_fwd(x, f(an_bias), f(an_logs), Wm.detach())
         z1 = out[:, :Ch]
         cin2 = cond if cond.shape[1] > 0 else None
-        h1 = conv2d_raw(z1, cin2, pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b), f(n1l), act)
-        h2 = conv2d_raw(h1, None, pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b), f(n2l), act)
-        o = zeros_conv_fwd(h2, w3, f(b3), f(l3))
+        pk = packs if packs is not None else (None,) * 6
+        ctx.packs = packs
+        h1 = conv2d_raw(z1, cin2, pk[0] if pk[0] is not None else pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b),
+                        f(n1l), act)
+        h2 = conv2d_raw(h1, None, pk[2] if pk[2] is not None else pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b),
+                        f(n2l), act)
+        o = zeros_conv_fwd(h2, w3, f(b3), f(l3), pk[4])
         dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
         affine_coupling_(out, o, f(scale), f(scale_shift), dlogdet, clamp_type, False)
         ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o)
@@ -425,25 +466,27 @@ class GlowStepFn(torch.autograd.Function):
         # ---- conv3 (Conv2dZeros) bwd
         go, gb3, gl3 = conv_epilogue_bwd(o, go, f(l3), 2, 0, arena=arena)
         gw3 = zeros_conv_wgrad(h2, go, C, k3, arena)
-        gh2 = conv2d_raw(go, None, pack_weight(w3, True), Hd, k3)
+        pk = ctx.packs if ctx.packs is not None else (None,) * 6
+        gh2 = conv2d_raw(go, None, pk[5] if pk[5] is not None else pack_weight(w3, True), Hd, k3)
         # ---- actnorm2 + act bwd, conv2 (1x1) bwd
         gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, f(n2l), 1, act, arena=arena)
         gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
-        gh1 = conv2d_raw(gh2, None, pack_weight(w2, True), Hd, k2)
+        gh1 = conv2d_raw(gh2, None, pk[3] if pk[3] is not None else pack_weight(w2, True), Hd, k2)
         # ---- actnorm1 + act bwd, conv1 bwd (grad flows to z1 (accumulated into gz's first half) and to cond)
         gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, f(n1l), 1, act, arena=arena)
         z1 = out[:, :Ch]
         has_cond = cond.shape[1] > 0
         gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
         gcond = torch.empty_like(cond) if has_cond else torch.zeros_like(cond)
-        conv2d_raw(gh1, None, pack_weight(w1, True), Ch + int(cond.shape[1]), int(w1.shape[2]), 0, None, None, 0,
-                   out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True, acc2=False)
+        conv2d_raw(gh1, None, pk[1] if pk[1] is not None else pack_weight(w1, True), Ch + int(cond.shape[1]), k1, 0,
+                   None, None, 0, out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True,
+                   acc2=False)
         # ---- invconv + actnorm bwd
         gx, gW, gab, gal = actnorm_invconv_bwd(x, f(an_bias), f(an_logs), Wm.detach(), gz, arena)
         return (gx, gcond, gW, gab.view(an_bias.shape), gal.view(an_logs.shape), gw1, gn1b.view(1, -1, 1, 1),
                 gn1l.view(n1l.shape), gw2, gn2b.view(1, -1, 1, 1), gn2l.view(n2l.shape), gw3, gb3, gl3.view(l3.shape),
                 None if gscale is None else gscale.view(scale.shape),
-                None if gshift is None else gshift.view(scale_shift.shape), None, None)
+                None if gshift is None else gshift.view(scale_shift.shape), None, None, None)
 
 
 class GlowStepRevFn(torch.autograd.Function):

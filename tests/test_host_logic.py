@@ -30,7 +30,7 @@ def test_c_abi_exports_every_declared_symbol():
     protos = _parse_header()
     assert len(protos) >= 20
     L = lib.load()
-    cmap = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "long": ctypes.c_long, "int": ctypes.c_int,
+    cmap = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "long": ctypes.c_long, "int": ctypes.c_int,
             "float": ctypes.c_float, "rfn_stream_t": ctypes.c_void_p}
     for name, args in protos.items():
         assert hasattr(L, name), "librfn_hip.so does not export %s" % name
