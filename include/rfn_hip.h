@@ -82,6 +82,18 @@ long rfn_packed_weight_size_bf16x3(int Cout, int Cin, int ks); /* in floats (4-b
 int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
                                 rfn_stream_t stream);
 
+/* Data-gradient convolution fused with the backward of the PRODUCER conv's Conv2dNorm epilogue (ActNorm + ActFun,
+ * glow_modules.py:139-142 + Utils/modules.py:8-19): with y = act((u+b)*exp(logs)) saved from the forward pass,
+ *   g  = conv(gin, wpk)                    (wpk packed with transpose_flip = 1 / mode 1)
+ *   out = g * act'(y) * exp(logs[c])       (= grad wrt u, what the producer's weight- and data-gradient consume)
+ *   part[row][c][0] = Σ out,  part[row][c][1] = Σ g*y   over the pixels of partial-sum row `row`
+ * so grad b = Σ_rows part[.,c,0] and grad logs = Σ_rows part[.,c,1] need only a tiny reduction afterwards.
+ * rows = rfn_conv2d_dgrad_act_rows_bf16x3(N,H,W,ks,Cout); part holds rows*Cout*2 floats; Cout % 64 == 0. */
+int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout);
+int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Cin, const float* wpk, const float* y, long y_ns,
+                                const float* logs, int act, float* out, long out_ns, float* part, int Cout, int N,
+                                int H, int W, int ks, rfn_stream_t stream);
+
 /* Pack MANY weights in one launch (a whole flow: ~300 descriptors per training step instead of ~370 launches).
  * descs_device: device array of n rfn_pack_desc; mode 0 forward, 1 data-gradient (transposed, taps mirrored),
  * 2 tap-expanded 1x1 form of a 3x3 conv with tiny Cout (w'[tap*Cout+co][ci] = w[co][ci][tap]).  Each wpk must hold

@@ -217,8 +217,8 @@ __global__ __launch_bounds__(256, RFN_CONV_WAVES) void conv_mfma_kernel(const Co
             const int co = blockIdx.y * BCO + c;
             float e0 = 0.f, e1 = 1.f;
             if (co < p.Cout) {
-                e0 = p.p0[co];
-                if (p.ep_mode == 1) e1 = expf(p.p1[co]);
+                if (p.ep_mode != 4) e0 = p.p0[co];
+                if (p.ep_mode == 1 || p.ep_mode == 4) e1 = expf(p.p1[co]);
                 if (p.ep_mode == 2) e1 = expf(3.f * p.p1[co]);
             }
             ep[c] = e0;

@@ -288,8 +288,8 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
             const int co = blockIdx.y * BCO + c;
             float e0 = 0.f, e1 = 1.f;
             if (co < p.Cout) {
-                e0 = p.p0[co];
-                if (p.ep_mode == 1) e1 = expf(p.p1[co]);
+                if (p.ep_mode != 4) e0 = p.p0[co];
+                if (p.ep_mode == 1 || p.ep_mode == 4) e1 = expf(p.p1[co]);
                 if (p.ep_mode == 2) e1 = expf(3.f * p.p1[co]);
             }
             ep[c] = e0;
@@ -346,7 +346,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
     }
 
     __syncthreads();
-    conv_epilogue<TCO, TPX, BCO>(p, acc, ep, co_base, wco, kk, HW, pn, ppix, pvalid);
+    conv_epilogue<TCO, TPX, BCO>(p, acc, ep, co_base, wco, kk, HW, pn, ppix, pvalid, blockIdx.x * WPX + wpx);
 }
 
 template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
@@ -375,7 +375,7 @@ static int launch_conv_b3(ConvParams& p, hipStream_t s) {
     const int HW = p.H * p.W;
     const bool dense = p.out1_ns == (long)p.cout_split * HW &&
                        (p.cout_split == p.Cout || p.out2_ns == (long)(p.Cout - p.cout_split) * HW);
-    if (wgs < 128 && nchunks >= 8 && p.ep_mode != 1 && !p.acc1 && !p.acc2 && dense) {
+    if (wgs < 128 && nchunks >= 8 && p.ep_mode != 1 && p.ep_mode != 4 && !p.acc1 && !p.acc2 && dense) {
         int ks_ = 512 / wgs;
         if (ks_ > nchunks / 2) ks_ = nchunks / 2;
         if (ks_ > 1) {
@@ -386,6 +386,48 @@ static int launch_conv_b3(ConvParams& p, hipStream_t s) {
     }
     grid.z = p.ksplit;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    return 0;
+}
+
+static int dispatch_conv_b3(ConvParams& p, int ks, hipStream_t s);
+
+// number of partial-sum rows rfn_conv2d_dgrad_act_bf16x3 writes for (N,H,W,ks,Cout): pixel tiles x waves along pixels
+extern "C" int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.N = N; p.H = H; p.W = W; p.Cout = Cout;
+    const bool few_px = (long)N * H * W * ((Cout + 127) / 128) < 256L * 128;
+    int BPX, WPX;
+    if (ks == 3) { BPX = few_px ? 64 : 128; WPX = 2; }
+    else if (few_px || Cout <= 64) { BPX = 64; WPX = 2; }
+    else if (Cout <= 128) { BPX = 128; WPX = 2; }
+    else { BPX = 64; WPX = 1; }
+    if (Cout <= 32) { BPX = 128; WPX = 4; }
+    int TWp, TH, TF;
+    tile_geometry(H, W, BPX, &TWp, &TH, &TF);
+    return ceil_div(W, TWp) * ceil_div(H, TH) * ceil_div(N, TF) * WPX;
+}
+
+// data-gradient conv fused with the backward of the producer's Conv2dNorm epilogue (ActNorm + activation):
+//   g  = conv(gin, wpk)                      (wpk packed with transpose_flip = 1)
+//   gu = g * act'(y) * exp(logs[c])          -> out        (y = saved forward activation, same shape as out)
+//   part[row][c][0] = Σ_pixels(row) gu ,  part[row][c][1] = Σ g*y     (row < rfn_conv2d_dgrad_act_rows_bf16x3(...))
+// Cout must be a multiple of 64.
+extern "C" int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Cin, const float* wpk, const float* y,
+                                           long y_ns, const float* logs, int act, float* out, long out_ns, float* part,
+                                           int Cout, int N, int H, int W, int ks, rfn_stream_t stream) {
+    RFN_CHECK_ARG(gin && wpk && y && logs && out && part && Cin > 0 && Cout > 0 && Cout % 64 == 0, -1);
+    RFN_CHECK_ARG((ks == 1 || ks == 3) && N >= 0 && H > 0 && W > 0 && ((uintptr_t)wpk & 15) == 0, -2);
+    if (N == 0) return 0;
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.in1 = gin; p.in1_ns = gin_ns; p.C1 = Cin; p.wpk = wpk; p.out1 = out; p.out1_ns = out_ns;
+    p.Cout = Cout; p.cout_split = Cout; p.N = N; p.H = H; p.W = W;
+    packed_dims_b3(Cout, Cin, &p.CoutP, &p.Cin8);
+    p.ep_mode = 4; p.act = act; p.p1 = logs; p.ybuf = y; p.ybuf_ns = y_ns; p.part = part;
+    int rc = dispatch_conv_b3(p, ks, (hipStream_t)stream);
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
     return 0;
 }
 
@@ -408,7 +450,14 @@ extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, cons
     p.N = N; p.H = H; p.W = W;
     packed_dims_b3(Cout, C1 + C2, &p.CoutP, &p.Cin8);
     p.ep_mode = ep_mode; p.act = act; p.p0 = p0; p.p1 = p1;
-    hipStream_t s = (hipStream_t)stream;
+    int rc = dispatch_conv_b3(p, ks, (hipStream_t)stream);
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int dispatch_conv_b3(ConvParams& p, int ks, hipStream_t s) {
+    const int Cout = p.Cout, N = p.N, H = p.H, W = p.W;
     const bool few_px = (long)N * H * W * ((Cout + 127) / 128) < 256L * 128;
     int rc;
     if (ks == 3) {
@@ -428,7 +477,5 @@ extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, cons
         else
             rc = launch_conv_b3<1, 4, 1, 2, 2, 32>(p, s);   // 256 co x 64 px: the input tile is read once for 256 couts
     }
-    if (rc) return rc;
-    RFN_LAUNCH_CHECK();
-    return 0;
+    return rc;
 }

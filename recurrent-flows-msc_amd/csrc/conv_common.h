@@ -27,7 +27,26 @@ struct ConvParams {
     int P2, P2_shift;  // (unused by the forward kernel; kept for layout compatibility)
     int ksplit;        // gridDim.z: the K (input channel chunk) range is split over z, partial sums meet by atomicAdd
     int w_lds_off;     // float offset of the weight tile inside dynamic LDS (16-byte aligned)
+    // ep_mode 4 (data-gradient conv fused with the backward of the producer's ActNorm+activation epilogue):
+    const float* ybuf;  // saved forward activation y = act((u+b)*exp(l)), same shape as the output
+    long ybuf_ns;
+    float* part;        // [gridDim.x * WPX][Cout][2] per-wave partial sums: Σ gu, Σ g*y
 };
+
+// Sum over each 32-lane half of a wave with DPP adds (VALU rate; __shfl_xor would go through the LDS crossbar, and the
+// fused activation-backward epilogue needs 128 of these per wave).  The total of lanes 0-31 lands in lanes 16-31, the
+// total of lanes 32-63 in lanes 48-63.
+__device__ __forceinline__ float half_wave_sum_dpp(float v) {
+#define RFN_DPP_ADD(ctrl, rmask)                                                                              \
+    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, true))
+    RFN_DPP_ADD(0xB1, 0xF);   // quad_perm [1,0,3,2]
+    RFN_DPP_ADD(0x4E, 0xF);   // quad_perm [2,3,0,1]
+    RFN_DPP_ADD(0x141, 0xF);  // row_half_mirror
+    RFN_DPP_ADD(0x140, 0xF);  // row_mirror      -> every lane of a 16-lane row holds the row total
+    RFN_DPP_ADD(0x142, 0xA);  // row_bcast15 into rows 1 and 3: += total of the previous row
+#undef RFN_DPP_ADD
+    return v;
+}
 
 // Epilogue shared by the fp32 and the bf16x3 kernels (the C/D register layout of the 32x32 MFMA tile does not depend
 // on the input dtype): per-channel affine + activation, bounds, output split over two tensors, accumulate / atomic.
@@ -35,9 +54,61 @@ template <int TCO, int TPX, int BCO>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TCO][TPX], const float* ep,
                                               const int co_base, const int wco, const int kk, const int HW,
                                               const int (&pn)[TPX], const int (&ppix)[TPX],
-                                              const bool (&pvalid)[TPX]) {
+                                              const bool (&pvalid)[TPX], const int prow = 0) {
     const int cl_base = wco * (32 * TCO) + 4 * kk;  // channel index inside the block for (a=0, r=0)
     const bool fast = (co_base + 32 * TCO <= p.Cout) && (p.cout_split == p.Cout);  // wave-uniform
+    if (p.ep_mode == 4) {
+        // g = this conv's result = grad wrt y = act((u+b)*exp(l)).  Emit gu = g*act'(y)*exp(l) (what the weight- and
+        // data-gradient of the producer conv consume) and this wave's per-channel Σ gu (-> grad b) and Σ g*y (-> grad l),
+        // so the separate elementwise+reduction pass over the 256-channel hidden tensors disappears.  Host guarantees
+        // full cout tiles, a single output tensor and no split-K.
+        if (co_base + 32 * TCO > p.Cout) return;  // whole wave past Cout (Cout % 64 == 0: never a partial tile)
+        const float* ybase[TPX];
+        float* obase[TPX];
+#pragma unroll
+        for (int t = 0; t < TPX; ++t) {
+            const long off = (long)(co_base + 4 * kk) * HW + ppix[t];
+            // masked pixels read frame 0 (always mapped) so that every load below is unconditional and batched
+            ybase[t] = pvalid[t] ? p.ybuf + pn[t] * p.ybuf_ns + off : p.ybuf + (long)(co_base + 4 * kk) * HW;
+            obase[t] = p.out1 + pn[t] * p.out1_ns + off;
+        }
+        const int l31 = threadIdx.x & 31;
+#pragma unroll
+        for (int a = 0; a < TCO; ++a) {
+            float yv[16][TPX];
+#pragma unroll
+            for (int r = 0; r < 16; ++r)
+#pragma unroll
+                for (int t = 0; t < TPX; ++t)
+                    yv[r][t] = ybase[t][(long)(a * 32 + (r & 3) + 8 * (r >> 2)) * HW];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int cidx = a * 32 + (r & 3) + 8 * (r >> 2);
+                const float e1 = ep[BCO + cl_base + cidx];
+                float sb = 0.f, sl = 0.f;
+#pragma unroll
+                for (int t = 0; t < TPX; ++t) {
+                    const float g = acc[a][t][r];
+                    const float y = yv[r][t];
+                    float slope = 1.f;
+                    if (p.act == 1) slope = y > 0.f ? 1.f : 0.f;
+                    if (p.act == 2) slope = y > 0.f ? 1.f : 0.2f;
+                    const float gu = pvalid[t] ? g * slope * e1 : 0.f;
+                    if (pvalid[t]) obase[t][(long)cidx * HW] = gu;
+                    sb += gu;
+                    sl += pvalid[t] ? g * y : 0.f;
+                }
+                sb = half_wave_sum_dpp(sb);  // lanes of one 32-lane half share the channel
+                sl = half_wave_sum_dpp(sl);
+                if (l31 == 16) {
+                    float* dst = p.part + ((long)prow * p.Cout + co_base + cidx + 4 * kk) * 2;
+                    dst[0] = sb;
+                    dst[1] = sl;
+                }
+            }
+        }
+        return;
+    }
     if (fast) {
         float* obase[TPX];
 #pragma unroll

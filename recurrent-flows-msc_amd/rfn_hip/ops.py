@@ -121,6 +121,25 @@ def pack_weight(w, flip=False):
     return wpk
 
 
+def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks):
+    """data-gradient conv + backward through the producer's ActNorm/activation in one kernel
+    (rfn_conv2d_dgrad_act_bf16x3).  Returns (gu, grad_bias[Cout], grad_logs[Cout])."""
+    N, Cin, H, W = gin.shape
+    gp, gns = L.frames(gin, "gin")
+    yp, yns = L.frames(y, "y")
+    gu = torch.empty((N, Cout, H, W), device=gin.device, dtype=torch.float32)
+    up, uns = L.frames(gu, "gu")
+    rows = L.load().rfn_conv2d_dgrad_act_rows_bf16x3(N, H, W, ks, Cout)
+    part = torch.empty((rows, Cout, 2), device=gin.device, dtype=torch.float32)
+    L.call("rfn_conv2d_dgrad_act_bf16x3", gp, _l(gns), _i(Cin), L.dev(wpk_flip), yp, _l(yns), L.dev(logs), _i(act), up,
+           _l(uns), L.dev(part), _i(Cout), _i(N), _i(H), _i(W), _i(ks),
+           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W) + "+actbwd", 2.0 * N * H * W * Cin * Cout * ks * ks,
+                 "N%d %d->%d %dx%d k%d dgrad+actbwd" % (N, Cin, Cout, H, W, ks),
+                 4.0 * (N * H * W * (Cin + 2 * Cout) + Cin * Cout * ks * ks)))
+    sums = part.sum(0)
+    return gu, sums[:, 0], sums[:, 1]
+
+
 class PackPlan:
     """Persistent packed-weight buffers for a list of (weight, mode) and ONE launch that refreshes all of them
     (rfn_pack_conv_weights_batched_bf16x3).  mode: 0 forward, 1 data-gradient, 2 tap-expanded 1x1 (tiny-Cout 3x3)."""
@@ -467,13 +486,21 @@ class GlowStepFn(torch.autograd.Function):
         go, gb3, gl3 = conv_epilogue_bwd(o, go, f(l3), 2, 0, arena=arena)
         gw3 = zeros_conv_wgrad(h2, go, C, k3, arena)
         pk = ctx.packs if ctx.packs is not None else (None,) * 6
-        gh2 = conv2d_raw(go, None, pk[5] if pk[5] is not None else pack_weight(w3, True), Hd, k3)
-        # ---- actnorm2 + act bwd, conv2 (1x1) bwd
-        gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, f(n2l), 1, act, arena=arena)
-        gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
-        gh1 = conv2d_raw(gh2, None, pk[3] if pk[3] is not None else pack_weight(w2, True), Hd, k2)
-        # ---- actnorm1 + act bwd, conv1 bwd (grad flows to z1 (accumulated into gz's first half) and to cond)
-        gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, f(n1l), 1, act, arena=arena)
+        w3f = pk[5] if pk[5] is not None else pack_weight(w3, True)
+        w2f = pk[3] if pk[3] is not None else pack_weight(w2, True)
+        if CONV_PRECISION == "bf16x3" and Hd % 64 == 0:
+            # data-gradient convs with the backward of the producer's ActNorm+activation fused into their epilogue
+            gh2, gn2b, gn2l = conv2d_dgrad_act(go, w3f, h2, f(n2l), act, Hd, k3)
+            gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
+            gh1, gn1b, gn1l = conv2d_dgrad_act(gh2, w2f, h1, f(n1l), act, Hd, k2)
+        else:
+            gh2 = conv2d_raw(go, None, w3f, Hd, k3)
+            # ---- actnorm2 + act bwd, conv2 (1x1) bwd
+            gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, f(n2l), 1, act, arena=arena)
+            gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
+            gh1 = conv2d_raw(gh2, None, w2f, Hd, k2)
+            # ---- actnorm1 + act bwd, conv1 bwd (grad flows to z1 (accumulated into gz's first half) and to cond)
+            gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, f(n1l), 1, act, arena=arena)
         z1 = out[:, :Ch]
         has_cond = cond.shape[1] > 0
         gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)

@@ -325,3 +325,40 @@ def test_graph_captured_step_equals_eager_step():
         if n in eager:
             torch.testing.assert_close(p.grad, eager[n], rtol=1e-4, atol=1e-5 * float(eager[n].abs().max()) + 1e-7,
                                        msg=lambda m: n + ": " + m)
+
+
+def test_glowstep_hd64_gradients_vs_oracle(conv_precision):
+    """hidden width 64 takes the fused data-gradient + activation-backward kernels (the golden fixtures use 16)."""
+    from Flow import GlowStep
+    from tests.golden_args import GLOW_DEFAULTS
+    a = dict(GLOW_DEFAULTS)
+    a["n_units_affine"] = 64
+    torch.manual_seed(12)
+    gs = GlowStep([3, 8, 8, 8], [3, 6, 8, 8], glow_ns(a)).cuda().train()
+    g = torch.Generator().manual_seed(13)
+    x0 = torch.randn(3, 8, 8, 8, generator=g)
+    c0 = torch.randn(3, 6, 8, 8, generator=g)
+    gs(cu(x0), cu(c0), torch.zeros(3, device="cuda"), False)  # data dependent init
+    with torch.no_grad():
+        for prm in gs.parameters():
+            prm.add_(0.05 * torch.randn(prm.shape, generator=g).cuda())
+    x = cu(x0).requires_grad_(True)
+    c = cu(c0).requires_grad_(True)
+    y, ld = gs(x, c, torch.zeros(3, device="cuda"), False)
+    wgt = torch.randn(y.shape, generator=g)
+    gld = torch.tensor([0.7, -0.4, 1.3])
+    ((y * cu(wgt)).sum() + (ld * cu(gld)).sum()).backward()
+    # oracle on the same parameters
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in gs.state_dict().items()}
+    xo = x0.clone().requires_grad_(True)
+    co = c0.clone().requires_grad_(True)
+    yo, ldo = O.glowstep(sd, "", xo, co, torch.zeros(3), False, True)
+    ((yo * wgt).sum() + (ldo * gld).sum()).backward()
+    close(y, yo.detach(), 1e-4, 1e-5)
+    close(ld, ldo.detach(), 1e-4, 1e-5)
+    close(x.grad, xo.grad, 2e-3, 1e-5)
+    close(c.grad, co.grad, 2e-3, 1e-5)
+    for k, p in gs.named_parameters():
+        ref = sd[k].grad
+        torch.testing.assert_close(p.grad.cpu(), ref, rtol=3e-3, atol=3e-4 * float(ref.abs().max()) + 1e-6,
+                                   msg=lambda m: k + ": " + m)
