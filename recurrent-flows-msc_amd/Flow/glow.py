@@ -187,9 +187,10 @@ class ListGlow(nn.Module):
         for l, (squeeze, steps, split) in enumerate(self._level_steps()):
             z = squeeze(z, undo_squeeze=False)
             W, c = self._batched_invconv(steps, z.shape[2] * z.shape[3])
+            Wk = W.unbind(0) if W is not None else None  # one stack-backward instead of K select-backward + K adds
             for k, step in enumerate(steps):
                 if W is not None:
-                    z, _ = step(z, condition[l], logdet=logdet, reverse=False, Wm=W[k], defer_logdet=dls,
+                    z, _ = step(z, condition[l], logdet=logdet, reverse=False, Wm=Wk[k], defer_logdet=dls,
                                 packs=None if packs is None else packs[step])
                 else:
                     z, logdet = step(z, condition[l], logdet=logdet, reverse=False)

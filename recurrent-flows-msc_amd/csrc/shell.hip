@@ -286,12 +286,97 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
     }
 }
 
+// Small channel counts (the two finest flow levels, C = 4 and 8, where N*HW is largest): one thread per pixel, all
+// C values in registers, every parameter-gradient partial in registers across a grid-stride sweep; the block's
+// C*C + 2C sums meet through wave shuffles + LDS and reach global memory as one atomic each.
+template <int C>
+__global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
+    const float* __restrict__ x, long x_ns, const float* __restrict__ bias, const float* __restrict__ logs,
+    const float* __restrict__ Wm, const float* __restrict__ gz, long gz_ns, float* __restrict__ gx, long gx_ns,
+    float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ glogs, int N, int HW) {
+    __shared__ float red[C * C + 2 * C];
+    for (int e = threadIdx.x; e < C * C + 2 * C; e += 256) red[e] = 0.f;
+    __syncthreads();
+    float w[C][C], b[C], es[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        b[i] = bias[i];
+        es[i] = expf(logs[i]);
+#pragma unroll
+        for (int j = 0; j < C; ++j) w[i][j] = Wm[i * C + j];
+    }
+    float aW[C][C], ab[C], al[C];
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+        ab[i] = 0.f;
+        al[i] = 0.f;
+#pragma unroll
+        for (int j = 0; j < C; ++j) aW[i][j] = 0.f;
+    }
+    const long total = (long)N * HW;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long n = q / HW;
+        const int p = (int)(q - n * HW);
+        float y[C], g[C];
+#pragma unroll
+        for (int c = 0; c < C; ++c) {
+            y[c] = (x[n * x_ns + (long)c * HW + p] + b[c]) * es[c];
+            g[c] = gz[n * gz_ns + (long)c * HW + p];
+        }
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            float gy = 0.f;
+#pragma unroll
+            for (int i = 0; i < C; ++i) {
+                gy = fmaf(w[i][j], g[i], gy);
+                aW[i][j] = fmaf(g[i], y[j], aW[i][j]);
+            }
+            const float gxv = gy * es[j];
+            gx[n * gx_ns + (long)j * HW + p] = gxv;
+            ab[j] += gxv;
+            al[j] = fmaf(gy, y[j], al[j]);
+        }
+    }
+    const bool lead = (threadIdx.x & 63) == 0;
+#pragma unroll
+    for (int i = 0; i < C; ++i) {
+#pragma unroll
+        for (int j = 0; j < C; ++j) {
+            const float v = wave_sum(aW[i][j]);
+            if (lead) atomicAdd(&red[i * C + j], v);
+        }
+        const float vb = wave_sum(ab[i]), vl = wave_sum(al[i]);
+        if (lead) {
+            atomicAdd(&red[C * C + i], vb);
+            atomicAdd(&red[C * C + C + i], vl);
+        }
+    }
+    __syncthreads();
+    for (int e = threadIdx.x; e < C * C; e += 256) atomicAdd(&gW[e], red[e]);
+    if (threadIdx.x < C) {
+        atomicAdd(&gbias[threadIdx.x], red[C * C + threadIdx.x]);
+        atomicAdd(&glogs[threadIdx.x], red[C * C + C + threadIdx.x]);
+    }
+}
+
 extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const float* bias, const float* logs,
                                            const float* Wm, const float* gz, long gz_ns, float* gx, long gx_ns,
                                            float* gW, float* gbias, float* glogs, int N, int C, int HW,
                                            rfn_stream_t stream) {
     RFN_CHECK_ARG(x && bias && logs && Wm && gz && gx && gW && gbias && glogs && N >= 0 && C > 0 && HW > 0, -1);
     if (N == 0) return 0;
+    if (C == 4 || C == 8) {
+        long tot = (long)N * HW;
+        int grid = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);
+        if (C == 4)
+            hipLaunchKernelGGL(actnorm_invconv_bwd_small_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, x_ns,
+                               bias, logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW);
+        else
+            hipLaunchKernelGGL(actnorm_invconv_bwd_small_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, x_ns,
+                               bias, logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW);
+        RFN_LAUNCH_CHECK();
+        return 0;
+    }
     int PB = 256;
     const size_t extra = ((size_t)C * C + 2 * C) * 4;
     while ((size_t)2 * C * (PB + 1) * 4 + extra > 65536 && PB > 64) PB >>= 1;
@@ -384,53 +469,46 @@ extern "C" int rfn_affine_coupling_f32(float* z, long z_ns, const float* o, long
     return 0;
 }
 
-// backward: a block owns frames n = blockIdx.x, +gridDim.x, ...; each wave walks channels j = wave, wave+4, ... and for
-// a channel sweeps the block's frames, so the per-channel parameter sums stay in registers and reach global memory as
-// one atomic pair per (block, channel).
+// backward: grid (X, C/2).  Block (bx, j) sweeps channel j over a strided share of the N*HW (frame, pixel) pairs —
+// every thread busy at every level (C/2 = 2 at the finest level), per-channel parameter sums in registers, one atomic
+// pair per block.
 __global__ __launch_bounds__(256) void affine_coupling_bwd_kernel(
     const float* __restrict__ zout, long zout_ns, const float* __restrict__ o, long o_ns,
     const float* __restrict__ gout, long gout_ns, const float* __restrict__ glogdet, const float* __restrict__ scale,
     const float* __restrict__ scale_shift, float* __restrict__ gz, long gz_ns, float* __restrict__ go, long go_ns,
     float* __restrict__ gscale, float* __restrict__ gscale_shift, int clamp_type, int N, int C, int HW) {
-    const int Ch = C >> 1;
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    for (int j = wave; j < Ch; j += 4) {
-        float sc = 0.f, sh = 0.f;
+    __shared__ float sm[4];
+    const int Ch = C >> 1, j = blockIdx.y;
+    float sc = 0.f, sh = 0.f;
+    if (clamp_type == 0) {
+        sc = scale[j];
+        sh = scale_shift[j];
+    }
+    float a_sc = 0.f, a_sh = 0.f;
+    const long total = (long)N * HW;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long n = q / HW;
+        const int p = (int)(q - n * HW);
+        const float s = o[n * o_ns + (long)(2 * j + 1) * HW + p];
+        const float ls = clamp_ls(s, clamp_type, sc, sh);
+        const float e = expf(ls);
+        const float g = gout[n * gout_ns + (long)(Ch + j) * HW + p];
+        const float gls = g * zout[n * zout_ns + (long)(Ch + j) * HW + p] + (glogdet ? glogdet[n] : 0.f);
+        const float gzv = g * e;
+        gz[n * gz_ns + (long)(Ch + j) * HW + p] = gzv;
+        go[n * go_ns + (long)(2 * j) * HW + p] = gzv;  // d/dshift
+        go[n * go_ns + (long)(2 * j + 1) * HW + p] = gls * clamp_ls_grad(s, clamp_type, sc);
         if (clamp_type == 0) {
-            sc = scale[j];
-            sh = scale_shift[j];
+            a_sc += gls * tanhf(s);
+            a_sh += gls;
         }
-        float a_sc = 0.f, a_sh = 0.f;
-        for (int n = blockIdx.x; n < N; n += gridDim.x) {
-            const float* z2o = zout + n * zout_ns + (long)(Ch + j) * HW;
-            const float* g2 = gout + n * gout_ns + (long)(Ch + j) * HW;
-            const float* on = o + n * o_ns + (long)(2 * j) * HW;
-            float* gz2 = gz + n * gz_ns + (long)(Ch + j) * HW;
-            float* gon = go + n * go_ns + (long)(2 * j) * HW;
-            const float gld = glogdet ? glogdet[n] : 0.f;
-            for (int p = lane; p < HW; p += 64) {
-                const float s = on[HW + p];
-                const float ls = clamp_ls(s, clamp_type, sc, sh);
-                const float e = expf(ls);
-                const float g = g2[p];
-                const float gls = g * z2o[p] + gld;
-                const float gzv = g * e;
-                gz2[p] = gzv;
-                gon[p] = gzv;  // d/dshift
-                gon[HW + p] = gls * clamp_ls_grad(s, clamp_type, sc);
-                if (clamp_type == 0) {
-                    a_sc += gls * tanhf(s);
-                    a_sh += gls;
-                }
-            }
-        }
-        if (clamp_type == 0) {
-            a_sc = wave_sum(a_sc);
-            a_sh = wave_sum(a_sh);
-            if (lane == 0) {
-                atomicAdd(&gscale[j], a_sc);
-                atomicAdd(&gscale_shift[j], a_sh);
-            }
+    }
+    if (clamp_type == 0) {
+        const float t_sc = block_sum_256(a_sc, sm);
+        const float t_sh = block_sum_256(a_sh, sm);
+        if (threadIdx.x == 0) {
+            atomicAdd(&gscale[j], t_sc);
+            atomicAdd(&gscale_shift[j], t_sh);
         }
     }
 }
@@ -442,9 +520,16 @@ extern "C" int rfn_affine_coupling_bwd_f32(const float* zout, long zout_ns, cons
     RFN_CHECK_ARG(zout && o && gout && gz && go && N >= 0 && C > 0 && (C % 2 == 0) && HW > 0, -1);
     RFN_CHECK_ARG(clamp_type != 0 || (scale && scale_shift && gscale && gscale_shift), -2);
     if (N == 0) return 0;
-    hipLaunchKernelGGL(affine_coupling_bwd_kernel, dim3(N < 304 ? N : 304), dim3(256), 0, (hipStream_t)stream, zout,
-                       zout_ns, o, o_ns, gout, gout_ns, glogdet, scale, scale_shift, gz, gz_ns, go, go_ns, gscale,
-                       gscale_shift, clamp_type, N, C, HW);
+    {
+        const int Ch = C / 2;
+        long tot = (long)N * HW;
+        int gx_ = (int)((tot + 255) / 256);
+        int cap = 2048 / Ch < 1 ? 1 : 2048 / Ch;
+        if (gx_ > cap) gx_ = cap;
+        hipLaunchKernelGGL(affine_coupling_bwd_kernel, dim3(gx_, Ch), dim3(256), 0, (hipStream_t)stream, zout, zout_ns, o,
+                           o_ns, gout, gout_ns, glogdet, scale, scale_shift, gz, gz_ns, go, go_ns, gscale, gscale_shift,
+                           clamp_type, N, C, HW);
+    }
     RFN_LAUNCH_CHECK();
     return 0;
 }
