@@ -74,12 +74,12 @@ def kernel_roofline(rec, steps):
         if meta:
             g["flops"] += meta[2]
             g["bytes"] += meta[4]
-            h = shapes.setdefault(meta[1] + " | " + meta[3], {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+            h = shapes.setdefault(str(meta[1]) + " | " + str(meta[3]), {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
             h["calls"] += 1
             h["ms"] += ms
             h["flops"] += meta[2]
             h["bytes"] += meta[4]
-    mfma = {k: v for k, v in groups.items() if v["flops"] > 0}
+    mfma = {k: v for k, v in groups.items() if v["flops"] > 0}  # (shell kernels carry bytes only)
     dom = max(mfma, key=lambda k: mfma[k]["ms"])
     d = mfma[dom]
     tot_ms = sum(v["ms"] for v in groups.values())

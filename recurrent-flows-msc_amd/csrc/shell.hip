@@ -219,26 +219,22 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
     const int t = threadIdx.x;
     const int E = C * C;
     for (int e = t; e < E + 2 * C; e += 256) Wacc[e] = 0.f;
+    // all 256 threads stage: thread = (pixel px, channel group cg); PB is a power of two <= 256
+    const int px = t & (PB - 1), cg = t / PB, ncg = 256 / PB;
     const long total = (long)N * HW;
     for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
-        const long q = (long)tile * PB + t;
-        const bool valid = t < PB && q < total;
-        int n = 0, p = 0;
-        if (valid) {
-            n = (int)(q / HW);
-            p = (int)(q % HW);
-        }
+        const long q = (long)tile * PB + px;
+        const bool valid = q < total;
+        const long qq = valid ? q : 0;  // masked pixels read pixel 0 (always mapped) and are zeroed after the load
+        const int n = (int)(qq / HW), p = (int)(qq % HW);
         __syncthreads();  // previous tile fully consumed (also orders the accumulator zeroing)
-        if (t < PB) {
-            for (int c = 0; c < C; ++c) {
-                float yv = 0.f, gv = 0.f;
-                if (valid) {
-                    yv = (x[n * x_ns + (long)c * HW + p] + bias[c]) * expf(logs[c]);
-                    gv = gz[n * gz_ns + (long)c * HW + p];
-                }
-                Y[c * PBS + t] = yv;
-                G[c * PBS + t] = gv;
-            }
+        const float* xs = x + n * x_ns + p;
+        const float* gs = gz + n * gz_ns + p;
+#pragma unroll 8
+        for (int c = cg; c < C; c += ncg) {
+            const float xv = xs[(long)c * HW], gv = gs[(long)c * HW];
+            Y[c * PBS + px] = valid ? (xv + bias[c]) * expf(logs[c]) : 0.f;
+            G[c * PBS + px] = valid ? gv : 0.f;
         }
         __syncthreads();
         // gW[i][j] += Σ_p gz_i(p) y_j(p): small C -> 256/(C*C) threads per entry split the pixels (LDS atomic
@@ -253,7 +249,8 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
                 atomicAdd(&Wacc[e], a);
             }
         } else {
-            for (int e = t; e < E; e += 256) {
+            // entries are split over blockIdx.y (deep levels have few pixel tiles: 38 at the 2x2 level)
+            for (int e = blockIdx.y * 256 + t; e < E; e += 256 * gridDim.y) {
                 const float* gi = G + (e / C) * PBS;
                 const float* yj = Y + (e % C) * PBS;
                 float a = 0.f;
@@ -262,15 +259,16 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
             }
         }
         // gy_j = Σ_i W[i][j] gz_i ; gx_j = gy_j * exp(logs_j) ; gbias_j += Σ gx_j ; glogs_j += Σ gy_j y_j.
-        // PB is a multiple of 64: whole waves are in or out, so wave_sum sees all 64 lanes; tail pixels are zeros.
-        if (t < PB) {
-            for (int j = 0; j < C; ++j) {
+        // Thread (px, cg) takes output channels j = cg, cg+ncg, ...: j is wave-uniform (PB >= 64), so W comes through the
+        // scalar cache and wave_sum adds over 64 pixels; masked pixels hold zeros.
+        if (blockIdx.y == 0) {
+            for (int j = cg; j < C; j += ncg) {
                 float a = 0.f;
-                for (int i = 0; i < C; ++i) a = fmaf(Wm[(long)i * C + j], G[i * PBS + t], a);
+                for (int i = 0; i < C; ++i) a = fmaf(Wm[(long)i * C + j], G[i * PBS + px], a);
                 const float gxv = a * expf(logs[j]);
                 if (valid) gx[n * gx_ns + (long)j * HW + p] = gxv;
                 const float s1 = wave_sum(gxv);
-                const float s2 = wave_sum(a * Y[j * PBS + t]);
+                const float s2 = wave_sum(a * Y[j * PBS + px]);
                 if ((t & 63) == 0) {
                     atomicAdd(&Bacc[j], s1);
                     atomicAdd(&Lacc[j], s2);
@@ -279,10 +277,12 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
         }
     }
     __syncthreads();
-    for (int e = t; e < E; e += 256) atomicAdd(&gW[e], Wacc[e]);
-    for (int c = t; c < C; c += 256) {
-        atomicAdd(&gbias[c], Bacc[c]);
-        atomicAdd(&glogs[c], Lacc[c]);
+    for (int e = blockIdx.y * 256 + t; e < E; e += 256 * gridDim.y) atomicAdd(&gW[e], Wacc[e]);  // owned entries
+    if (blockIdx.y == 0) {
+        for (int c = t; c < C; c += 256) {
+            atomicAdd(&gbias[c], Bacc[c]);
+            atomicAdd(&glogs[c], Lacc[c]);
+        }
     }
 }
 
@@ -367,7 +367,8 @@ extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const floa
     if (N == 0) return 0;
     if (C == 4 || C == 8) {
         long tot = (long)N * HW;
-        int grid = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);
+        // few, fat blocks: every block ends with C*C+2C same-address atomics, which serialise at the memory side
+        int grid = (int)((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256);
         if (C == 4)
             hipLaunchKernelGGL(actnorm_invconv_bwd_small_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, x_ns,
                                bias, logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW);
@@ -391,8 +392,10 @@ extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const floa
     long tot = (long)N * HW;
     int ntiles = (int)((tot + PB - 1) / PB);
     int grid = ntiles < 512 ? ntiles : 512;
-    hipLaunchKernelGGL(actnorm_invconv_bwd_kernel, dim3(grid), dim3(256), lds, (hipStream_t)stream, x, x_ns, bias, logs,
-                       Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB, ntiles);
+    int ny = (C * C > 256) ? (C * C + 511) / 512 : 1;
+    while (ny > 1 && grid * ny > 2048) ny >>= 1;
+    hipLaunchKernelGGL(actnorm_invconv_bwd_kernel, dim3(grid, ny), dim3(256), lds, (hipStream_t)stream, x, x_ns, bias,
+                       logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB, ntiles);
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -524,7 +527,7 @@ extern "C" int rfn_affine_coupling_bwd_f32(const float* zout, long zout_ns, cons
         const int Ch = C / 2;
         long tot = (long)N * HW;
         int gx_ = (int)((tot + 255) / 256);
-        int cap = 2048 / Ch < 1 ? 1 : 2048 / Ch;
+        int cap = 512 / Ch < 1 ? 1 : 512 / Ch;
         if (gx_ > cap) gx_ = cap;
         hipLaunchKernelGGL(affine_coupling_bwd_kernel, dim3(gx_, Ch), dim3(256), 0, (hipStream_t)stream, zout, zout_ns, o,
                            o_ns, gout, gout_ns, glogdet, scale, scale_shift, gz, gz_ns, go, go_ns, gscale, gscale_shift,

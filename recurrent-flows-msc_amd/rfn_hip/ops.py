@@ -94,7 +94,8 @@ def actnorm_invconv_bwd(x, bias, logs, Wm, gz, arena=None):
     gl = _zeros(arena, C, device=x.device)
     L.call("rfn_actnorm_invconv_bwd_f32", xp, _l(xns), L.dev(bias.contiguous()), L.dev(logs.contiguous()),
            L.dev(Wm.contiguous()), gzp, _l(gzns), gxp, _l(gxns), L.dev(gW), L.dev(gb), L.dev(gl), _i(N), _i(C),
-           _i(_hw(x)))
+           _i(_hw(x)), meta=("shell", "actnorm_invconv_bwd", 0.0, "N%d C%d HW%d" % (N, C, _hw(x)),
+                             12.0 * N * C * _hw(x)))
     return gx, gW, gb, gl
 
 
