@@ -362,3 +362,70 @@ def test_glowstep_hd64_gradients_vs_oracle(conv_precision):
         ref = sd[k].grad
         torch.testing.assert_close(p.grad.cpu(), ref, rtol=3e-3, atol=3e-4 * float(ref.abs().max()) + 1e-6,
                                    msg=lambda m: k + ": " + m)
+
+
+def test_flow_bijection_single_level():
+    """with L = 1 there is no Split2d re-sampling, so g(f(x)) = x (the reference's 'bijection check',
+    RFN_new.py:437-439, asserted here)."""
+    from Flow import ListGlow
+    from tests.golden_args import GLOW_DEFAULTS
+    a = dict(GLOW_DEFAULTS)
+    a.update(L=1, K=3, n_units_affine=64)
+    torch.manual_seed(5)
+    flow = ListGlow([4, 3, 16, 16], [[4, 6, 8, 8]], (4, 12, 8, 8), glow_ns(a)).cuda().train()
+    g = torch.Generator().manual_seed(6)
+    x = (torch.rand(4, 3, 16, 16, generator=g) - 0.5).cuda()
+    cond = [torch.randn(4, 6, 8, 8, generator=g).cuda()]
+    base = torch.randn(4, 12, 8, 8, generator=g).cuda()
+    noise = torch.zeros_like(x)
+    flow.log_prob(x, cond, base, 0, noise=noise)  # data dependent init
+    with torch.no_grad():
+        for prm in flow.parameters():
+            prm.add_(0.05 * torch.randn(prm.shape, generator=g).cuda())
+        z, nll = flow.log_prob(x, cond, base, 0, noise=noise)
+        xb = flow.sample(z, cond, base, temperature=1.0)
+    assert torch.isfinite(nll).all()
+    close(xb, x.cpu(), 2e-4, 2e-5)
+
+
+def test_canonical_size_properties():
+    """BASELINE sizes (N = 32*19 = 608 frames, level-0 GlowStep 4ch 32x32, cond 16ch, Hd 256): reverse(forward(x)) = x,
+    and the time-batched call equals the per-timestep calls (what the reference executes)."""
+    from Flow import GlowStep
+    from tests.golden_args import GLOW_DEFAULTS
+    a = dict(GLOW_DEFAULTS)
+    a["n_units_affine"] = 256
+    torch.manual_seed(7)
+    B, T1 = 32, 19
+    gs = GlowStep([B, 4, 32, 32], [B, 16, 32, 32], glow_ns(a)).cuda().train()
+    g = torch.Generator().manual_seed(8)
+    x = torch.randn(B * T1, 4, 32, 32, generator=g).cuda()
+    c = torch.randn(B * T1, 16, 32, 32, generator=g).cuda()
+    with torch.no_grad():
+        gs(x[:B], c[:B], torch.zeros(B, device="cuda"), False)  # init on the t = 1 batch
+        for prm in gs.parameters():
+            prm.add_(0.02 * torch.randn(prm.shape, generator=g).cuda())
+        y, ld = gs(x, c, torch.zeros(B * T1, device="cuda"), False)
+        xb, ldb = gs(y, c, ld.clone(), True)
+        assert float((xb - x).abs().max()) < 2e-4 * float(x.abs().max())
+        assert float(ldb.abs().max()) < 1e-4 * float(ld.abs().max()) + 1e-3
+        ys = torch.cat([gs(x[t * B:(t + 1) * B], c[t * B:(t + 1) * B], torch.zeros(B, device="cuda"), False)[0]
+                        for t in range(T1)])
+        assert torch.equal(ys, y)  # no reduction crosses a frame in the forward kernels: bit identical
+
+
+def test_generation_paths_run(golden):
+    """predict / sample / reconstruct (RFN_new.py:256-494) through the reverse kernels: shapes, finiteness, and
+    determinism of the conditioning frames."""
+    from RFN import RFN
+    f = golden("rfn_loss.pt")["plain"]
+    m = load_sd(RFN(Namespace(**f["args"])), f["sd"]).eval()
+    x = cu(f["x"])
+    true_x, preds = m.predict(x, n_predictions=3, n_conditions=2)
+    assert tuple(preds.shape) == (3,) + tuple(x[:, 0].shape) and torch.isfinite(preds).all()
+    assert torch.equal(true_x[0], f["x"][:, 0])
+    samples = m.sample(x, n_samples=2)
+    assert tuple(samples.shape) == (2,) + tuple(x[:, 0].shape) and torch.isfinite(samples).all()
+    recons, recons_flow = m.reconstruct(x)
+    assert tuple(recons.shape) == (f["T"],) + tuple(x[:, 0].shape)
+    assert torch.isfinite(recons).all() and torch.isfinite(recons_flow).all()
