@@ -13,6 +13,9 @@ Strong scaling: the global batch (32 sequences) is fixed and sharded over the ra
 import argparse
 import json
 import os
+# ROCm 7.2: with graph packet capture on, hipGraph memset nodes (PyTorch multi-block reductions zero their semaphores
+# with one) race with neighbouring kernel nodes on replay; must be set before the HIP runtime initialises.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import sys
 import time
 

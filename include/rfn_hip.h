@@ -179,6 +179,18 @@ int rfn_gauss_logp_bwd_f32(const float* z, long z_ns, const float* o, long o_ns,
 int rfn_gauss_sample_f32(const float* o, long o_ns, const float* eps, float* z, long z_ns, float temperature, int layout,
                          int std_mode, int N, int Cz, int HW, rfn_stream_t stream);
 
+/* ---- a10  SRNN latent step of RFN.loss (RFN/RFN_new.py:167-184,206-207 with SimpleParamNet's chunk + softplus,
+ * Utils/modules.py:240-244): enc, pri = [B, 2*Z*HW] outputs of the encoder / prior parameter convs (loc half | raw scale
+ * half); ps = softplus(pri_raw), es = softplus(enc_raw), pm = pri_loc, em = enc_loc (+ pm when res_q);
+ *   zt = pm + ps*eps_p,  zxt = em + es*eps_q,  kl = KL(N(em,es)||N(pm,ps)) element-wise,  em/es also returned.
+ * ZHW = Z*H*W.  The backward takes the gradients of the five outputs (any may be NULL) and writes g_enc, g_pri. */
+int rfn_latent_step_fwd_f32(const float* enc, const float* pri, const float* eps_p, const float* eps_q, float* zt,
+                            float* zxt, float* kl, float* em, float* es, int B, int ZHW, int res_q, rfn_stream_t stream);
+int rfn_latent_step_bwd_f32(const float* enc, const float* pri, const float* eps_p, const float* eps_q,
+                            const float* g_zt, const float* g_zxt, const float* g_kl, const float* g_em,
+                            const float* g_es, float* g_enc, float* g_pri, int B, int ZHW, int res_q,
+                            rfn_stream_t stream);
+
 /* ---- a9  ConvLSTMLayer.forward gate update  (Utils/modules.py:370-377): cc = conv output [N,4*Hc,HW] in gate order
  * i,f,o,g;  i=σ(cc_i+Wci∘c) f=σ(cc_f+Wcf∘c) g=tanh(cc_g) c'=f∘c+i∘g o=σ(cc_o+Wco∘c') h'=o∘tanh(c').
  * Wci/Wcf/Wco [Hc*HW] may be NULL (== 0, which is what the reference trains with).  gates [N,4*Hc,HW] receives the

@@ -16,6 +16,7 @@ import torch.nn as nn
 
 from Utils import split_feature, ActFun
 from rfn_hip import ops as K
+from rfn_hip import debug as D
 from .glow_modules import (ActNorm, Conv2dZeros, Conv2dNorm, InvConv, AffineCoupling, Squeeze2d, Split2d,
                            BatchNormFlow, add_logdet)
 
@@ -194,12 +195,17 @@ class ListGlow(nn.Module):
                                 packs=None if packs is None else packs[step])
                 else:
                     z, logdet = step(z, condition[l], logdet=logdet, reverse=False)
+                D.check("f.l%d.k%d.z" % (l, k), z)
+                if dls:
+                    D.check("f.l%d.k%d.dl" % (l, k), dls[-1])
             if W is not None:
                 # ActNorm logs are read AFTER the steps ran: the first training call initialises them in place
                 logs = torch.stack([s.norm.logs.reshape(-1) for s in steps])
                 const = const + c + logs.sum() * (z.shape[2] * z.shape[3])
             if split is not None:
                 z, logdet = split(z, condition[l], logdet=logdet, reverse=False)
+                D.check("f.l%d.split.z" % l, z); D.check("f.l%d.split.logdet" % l, logdet)
+        D.check("f.const", const if torch.is_tensor(const) else None)
         if logdet is not None and dls:
             logdet = logdet + torch.stack(dls).sum(0) + const
         return z, logdet
@@ -241,8 +247,10 @@ class ListGlow(nn.Module):
         x, obj_unif = self.uniform_binning_correction(x, noise)
         assert isinstance(condition, list), "Condition is not a list, make sure it fits L"
         z, obj = self.f(x, condition, logdet)
+        D.check("f.obj", obj)
         obj = obj + obj_unif
         params = self._base_params(base_condition, x.shape[0], x.device)
+        D.check("base_params", params)
         obj = obj + K.GaussLogpFn.apply(z.contiguous(), params, 1, 1)
         return z, -obj
 

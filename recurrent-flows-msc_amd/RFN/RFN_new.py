@@ -15,6 +15,8 @@ import torch.nn as nn
 
 from Flow import ListGlow
 from Flow.glow_modules import ActNorm
+from rfn_hip import ops as K
+from rfn_hip import debug as DBG
 from Utils import VGG_upscaler, VGG_downscaler, SimpleParamNet, ConvLSTM, free_bits_kl, batch_reduce
 
 
@@ -154,30 +156,34 @@ class RFN(nn.Module):
         else:
             feats = [[f[i * B:(i + 1) * B] for f in feats_tb] for i in range(T)]
         store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
+        for j, f in enumerate(feats_tb if not self.single_feature else [feats_tb]):
+            DBG.check("feat%d" % j, f)
+        DBG.check("ht_last", store_ht[T - 1] if len(store_ht) >= T else store_ht[-1])
 
         kl_loss = 0
         st_mean, st_std, st_zx = [], [], []
         base_t, noise_t = [], []
+        # all 2(T-1) reparameterisation draws of the loop in one launch
+        eps_all = None if draws is not None else torch.randn((T - 1, 2) + tuple(zprev.shape), device=dev)
         for i in range(1, T):
             ht = store_ht[i - 1]
             if self.enable_smoothing:
-                enc_mean, enc_std = self.encoder(torch.cat((store_at[i - 1], zxprev), dim=1))
+                enc_raw = self.encoder.raw(torch.cat((store_at[i - 1], zxprev), dim=1))
             else:
-                enc_mean, enc_std = self.encoder(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
-            if self.res_q:
-                prior_mean, prior_std = self.prior(torch.cat((ht, zxprev), dim=1))
-                enc_mean = prior_mean + enc_mean
-            else:
-                prior_mean, prior_std = self.prior(torch.cat((ht, zprev), dim=1))
-            zt = prior_mean + prior_std * eps_like(prior_mean)      # dist_prior.rsample()
-            zxt = enc_mean + enc_std * eps_like(enc_mean)           # dist_enc.rsample()
+                enc_raw = self.encoder.raw(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
+            pri_raw = self.prior.raw(torch.cat((ht, zxprev if self.res_q else zprev), dim=1))
+            # chunk + softplus, res_q shift, both reparameterised draws and the KL in one kernel (RNG order: prior first)
+            eps_p = eps_like(zprev) if eps_all is None else eps_all[i - 1, 0]
+            eps_q = eps_like(zprev) if eps_all is None else eps_all[i - 1, 1]
+            zt, zxt, kl_t, enc_mean, enc_std = K.LatentStepFn.apply(enc_raw, pri_raw, eps_p, eps_q, self.res_q)
+            DBG.check("enc_raw%d" % i, enc_raw); DBG.check("pri_raw%d" % i, pri_raw); DBG.check("zxt%d" % i, zxt)
             st_mean.append(enc_mean); st_std.append(enc_std); st_zx.append(zxprev)
             hz = torch.cat((ht, zxt), dim=1)
             base_t.append(hz)
             if draws is not None:
                 noise_t.append(draws.pop(0).to(dev))
             if self.D == 1:
-                kl_loss = kl_loss + kl_normal(enc_mean, enc_std, prior_mean, prior_std)
+                kl_loss = kl_loss + kl_t
             zprev, zxprev = zt, zxt
 
         # ---- the decoder: all B*(T-1) frames in one call, t-major
@@ -199,7 +205,10 @@ class RFN(nn.Module):
             with torch.no_grad():  # data dependent init on the t = 1 batch, as the reference's first call does
                 self.flow.log_prob(xs[:B], [c[:B] for c in conds], base[:B], 0,
                                    None if noise is None else noise[:B])
+        for j, c in enumerate(conds):
+            DBG.check("cond%d" % j, c)
         _, nll = self.flow.log_prob(xs, conds, base, logdet, noise)
+        DBG.check("nll", nll)
         nll_loss = nll.view(T - 1, B).sum(0)
 
         if self.D > 1:  # overshooting (RFN_new.py:213-240)

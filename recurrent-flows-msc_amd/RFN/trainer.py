@@ -157,6 +157,10 @@ class Solver(object):
         AccumulateGrad nodes are bound to the default stream and would pull it into the capture."""
         if not torch.cuda.is_available():
             return False
+        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
+            # see rfn_hip/__init__.py: replays are not trustworthy with packet capture on (memset nodes race)
+            self._graph_error = "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be exported before the HIP runtime starts"
+            return False
         try:
             self._g_draws = static_draws
             self._g_in = example_image.clone()
@@ -189,7 +193,10 @@ class Solver(object):
             return False
 
     def _graph_body(self):
+        from rfn_hip import debug as D
+        D.begin()
         image = self.preprocess(self._g_in)
+        D.check("image", image)
         kl_free_bit, kl, nll = self.model.loss(image, 0, draws=getattr(self, "_g_draws", None))
         loss = nll + self._g_beta * kl_free_bit
         loss.backward()

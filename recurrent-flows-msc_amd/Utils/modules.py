@@ -299,8 +299,12 @@ class SimpleParamNet(nn.Module):
         self.param_net = nn.Conv2d(in_channels, 2 * out_channels, kernel_size=3, stride=1, padding=1)
         self.softplus = nn.Softplus()
 
+    def raw(self, x):
+        """[B, 2*out, h, w] = (loc | raw scale) before the chunk + softplus of forward()."""
+        return self.param_net(self.net(x))
+
     def forward(self, x):
-        loc, log_scale = self.param_net(self.net(x)).chunk(2, 1)
+        loc, log_scale = self.raw(x).chunk(2, 1)
         return loc, self.softplus(log_scale)
 
 

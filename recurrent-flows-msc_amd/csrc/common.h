@@ -57,3 +57,15 @@ static inline int ilog2(int v) {
     while ((1 << l) < v) ++l;
     return l;
 }
+
+// Zero fill as an ordinary kernel node: hipMemsetAsync nodes inside a captured hipGraph were observed to race with the
+// neighbouring kernel nodes on replay (split-K outputs picked up stale values), so the library never enqueues memsets.
+static __global__ void rfn_zero_f32_kernel(float* __restrict__ p, long n) {
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = 0.f;
+}
+static inline void rfn_zero_f32(float* p, long n, hipStream_t s) {
+    if (n <= 0) return;
+    long blocks = (n + 1023) / 1024;
+    if (blocks > 1024) blocks = 1024;
+    hipLaunchKernelGGL(rfn_zero_f32_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p, n);
+}

@@ -380,8 +380,8 @@ static int launch_conv_b3(ConvParams& p, hipStream_t s) {
         if (ks_ > nchunks / 2) ks_ = nchunks / 2;
         if (ks_ > 1) {
             p.ksplit = ks_;
-            (void)hipMemsetAsync(p.out1, 0, (size_t)p.N * p.cout_split * HW * 4, s);
-            if (p.cout_split != p.Cout) (void)hipMemsetAsync(p.out2, 0, (size_t)p.N * (p.Cout - p.cout_split) * HW * 4, s);
+            rfn_zero_f32(p.out1, (long)p.N * p.cout_split * HW, s);
+            if (p.cout_split != p.Cout) rfn_zero_f32(p.out2, (long)p.N * (p.Cout - p.cout_split) * HW, s);
         }
     }
     grid.z = p.ksplit;

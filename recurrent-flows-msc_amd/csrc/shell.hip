@@ -778,6 +778,83 @@ extern "C" int rfn_tap_scatter_f32(const float* g, float* Gs, int N, int C, int 
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ SRNN latent step
+// RFN.loss per timestep (RFN_new.py:167-184,206-207): enc / pri are the outputs [B, 2*Z, HW] of the encoder / prior
+// parameter convs (loc | raw scale, "chunk(2,1)" halves, SimpleParamNet.forward Utils/modules.py:240-244):
+//   ps = softplus(pri_raw), es = softplus(enc_raw), pm = pri_loc, em = enc_loc (+ pm with res_q)
+//   zt = pm + ps*eps_p ;  zxt = em + es*eps_q ;  kl = KL(N(em,es) || N(pm,ps)) element-wise
+// One launch instead of ~25 tiny elementwise kernels per timestep (and ~50 in backward).
+__device__ __forceinline__ float sigmoid_sp(float raw) { return raw > 20.f ? 1.f : 1.f / (1.f + expf(-raw)); }
+
+__global__ void latent_step_fwd_kernel(const float* __restrict__ enc, const float* __restrict__ pri,
+                                       const float* __restrict__ eps_p, const float* __restrict__ eps_q,
+                                       float* __restrict__ zt, float* __restrict__ zxt, float* __restrict__ kl,
+                                       float* __restrict__ em_o, float* __restrict__ es_o, int B, int ZHW, int res_q) {
+    const long total = (long)B * ZHW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / ZHW, e = idx - b * ZHW;
+        const float pm = pri[b * 2 * ZHW + e], ps = softplusf_(pri[b * 2 * ZHW + ZHW + e]);
+        const float es = softplusf_(enc[b * 2 * ZHW + ZHW + e]);
+        const float em = enc[b * 2 * ZHW + e] + (res_q ? pm : 0.f);
+        zt[idx] = pm + ps * eps_p[idx];
+        zxt[idx] = em + es * eps_q[idx];
+        const float r = es / ps, d = (em - pm) / ps;
+        kl[idx] = 0.5f * (r * r + d * d - 1.f - logf(r * r));
+        em_o[idx] = em;
+        es_o[idx] = es;
+    }
+}
+__global__ void latent_step_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ pri,
+                                       const float* __restrict__ eps_p, const float* __restrict__ eps_q,
+                                       const float* __restrict__ g_zt, const float* __restrict__ g_zxt,
+                                       const float* __restrict__ g_kl, const float* __restrict__ g_em,
+                                       const float* __restrict__ g_es, float* __restrict__ g_enc,
+                                       float* __restrict__ g_pri, int B, int ZHW, int res_q) {
+    const long total = (long)B * ZHW;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long b = idx / ZHW, e = idx - b * ZHW;
+        const float praw = pri[b * 2 * ZHW + ZHW + e], eraw = enc[b * 2 * ZHW + ZHW + e];
+        const float pm = pri[b * 2 * ZHW + e], ps = softplusf_(praw), es = softplusf_(eraw);
+        const float em = enc[b * 2 * ZHW + e] + (res_q ? pm : 0.f);
+        const float gzt = g_zt ? g_zt[idx] : 0.f, gzx = g_zxt ? g_zxt[idx] : 0.f, gk = g_kl ? g_kl[idx] : 0.f;
+        const float ips = 1.f / ps, d = (em - pm) * ips * ips;  // (em-pm)/ps^2
+        const float d_em = gzx + gk * d + (g_em ? g_em[idx] : 0.f);
+        const float d_es = gzx * eps_q[idx] + gk * (es * ips * ips - 1.f / es) + (g_es ? g_es[idx] : 0.f);
+        float d_pm = gzt - gk * d;
+        const float d_ps = gzt * eps_p[idx] + gk * (ips - (es * es + (em - pm) * (em - pm)) * ips * ips * ips);
+        if (res_q) d_pm += d_em;
+        g_enc[b * 2 * ZHW + e] = d_em;
+        g_enc[b * 2 * ZHW + ZHW + e] = d_es * sigmoid_sp(eraw);
+        g_pri[b * 2 * ZHW + e] = d_pm;
+        g_pri[b * 2 * ZHW + ZHW + e] = d_ps * sigmoid_sp(praw);
+    }
+}
+extern "C" int rfn_latent_step_fwd_f32(const float* enc, const float* pri, const float* eps_p, const float* eps_q,
+                                       float* zt, float* zxt, float* kl, float* em, float* es, int B, int ZHW,
+                                       int res_q, rfn_stream_t stream) {
+    RFN_CHECK_ARG(enc && pri && eps_p && eps_q && zt && zxt && kl && em && es && B >= 0 && ZHW > 0, -1);
+    if (B == 0) return 0;
+    long tot = (long)B * ZHW;
+    int grid = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);
+    hipLaunchKernelGGL(latent_step_fwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc, pri, eps_p, eps_q, zt,
+                       zxt, kl, em, es, B, ZHW, res_q);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int rfn_latent_step_bwd_f32(const float* enc, const float* pri, const float* eps_p, const float* eps_q,
+                                       const float* g_zt, const float* g_zxt, const float* g_kl, const float* g_em,
+                                       const float* g_es, float* g_enc, float* g_pri, int B, int ZHW, int res_q,
+                                       rfn_stream_t stream) {
+    RFN_CHECK_ARG(enc && pri && eps_p && eps_q && g_enc && g_pri && B >= 0 && ZHW > 0, -1);
+    if (B == 0) return 0;
+    long tot = (long)B * ZHW;
+    int grid = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);
+    hipLaunchKernelGGL(latent_step_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc, pri, eps_p, eps_q,
+                       g_zt, g_zxt, g_kl, g_em, g_es, g_enc, g_pri, B, ZHW, res_q);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ ConvLSTM gates
 __global__ void convlstm_gates_fwd_kernel(const float* __restrict__ cc, const float* __restrict__ c_prev, long c_ns,
                                           const float* __restrict__ Wci, const float* __restrict__ Wcf,

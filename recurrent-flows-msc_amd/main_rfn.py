@@ -6,6 +6,12 @@ Multi-GPU: launch with `python -m torch.distributed.run --nproc-per-node N main_
 per GPU, the global batch is sharded over ranks and gradients are all-reduced with RCCL (see rfn_hip/dist.py).
 """
 import argparse
+import os
+
+# ROCm 7.2: with graph packet capture on, hipGraph memset nodes (PyTorch multi-block reductions zero their semaphores
+# with one) race with neighbouring kernel nodes on replay; must be set before the HIP runtime initialises.
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+
 
 
 def add_bool_arg(parser, name, help, default=False):

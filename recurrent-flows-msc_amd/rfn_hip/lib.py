@@ -54,6 +54,8 @@ SIGNATURES = {
     "rfn_gauss_logp_bwd_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i,
                                _c_s],
     "rfn_gauss_sample_f32": [_c_f, _c_l, _c_f, _c_f, _c_l, ctypes.c_float, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_latent_step_fwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_s],
+    "rfn_latent_step_bwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_s],
     "rfn_convlstm_gates_fwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,
                                    _c_s],
     "rfn_convlstm_gates_bwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f,

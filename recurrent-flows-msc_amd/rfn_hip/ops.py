@@ -55,8 +55,9 @@ def actnorm_invconv_fwd(x, bias, logs, Wm):
     xp, xns = L.frames(x, "x")
     z = torch.empty(x.shape, device=x.device, dtype=x.dtype)
     zp, zns = L.frames(z, "z")
-    L.call("rfn_actnorm_invconv_fwd_f32", xp, _l(xns), L.dev(bias.contiguous()), L.dev(logs.contiguous()),
-           L.dev(Wm.contiguous()), zp, _l(zns), _i(N), _i(C), _i(_hw(x)))
+    bias, logs, Wm = bias.contiguous(), logs.contiguous(), Wm.contiguous()  # held until the launch is enqueued
+    L.call("rfn_actnorm_invconv_fwd_f32", xp, _l(xns), L.dev(bias), L.dev(logs), L.dev(Wm), zp, _l(zns), _i(N), _i(C),
+           _i(_hw(x)))
     return z
 
 
@@ -92,8 +93,8 @@ def actnorm_invconv_bwd(x, bias, logs, Wm, gz, arena=None):
     gW = _zeros(arena, C, C, device=x.device)
     gb = _zeros(arena, C, device=x.device)
     gl = _zeros(arena, C, device=x.device)
-    L.call("rfn_actnorm_invconv_bwd_f32", xp, _l(xns), L.dev(bias.contiguous()), L.dev(logs.contiguous()),
-           L.dev(Wm.contiguous()), gzp, _l(gzns), gxp, _l(gxns), L.dev(gW), L.dev(gb), L.dev(gl), _i(N), _i(C),
+    bias, logs, Wm = bias.contiguous(), logs.contiguous(), Wm.contiguous()  # held until the launch is enqueued
+    L.call("rfn_actnorm_invconv_bwd_f32", xp, _l(xns), L.dev(bias), L.dev(logs), L.dev(Wm), gzp, _l(gzns), gxp, _l(gxns), L.dev(gW), L.dev(gb), L.dev(gl), _i(N), _i(C),
            _i(_hw(x)), meta=("shell", "actnorm_invconv_bwd", 0.0, "N%d C%d HW%d" % (N, C, _hw(x)),
                              12.0 * N * C * _hw(x)))
     return gx, gW, gb, gl
@@ -104,8 +105,9 @@ def invconv_actnorm_rev(z, bias, logs, Winv):
     zp, zns = L.frames(z, "z")
     x = torch.empty(z.shape, device=z.device, dtype=z.dtype)
     xp, xns = L.frames(x, "x")
-    L.call("rfn_invconv_actnorm_rev_f32", zp, _l(zns), L.dev(bias.contiguous()), L.dev(logs.contiguous()),
-           L.dev(Winv.contiguous()), xp, _l(xns), _i(N), _i(C), _i(_hw(z)))
+    bias, logs, Winv = bias.contiguous(), logs.contiguous(), Winv.contiguous()  # held until the launch is enqueued
+    L.call("rfn_invconv_actnorm_rev_f32", zp, _l(zns), L.dev(bias), L.dev(logs), L.dev(Winv), xp, _l(xns), _i(N), _i(C),
+           _i(_hw(z)))
     return x
 
 
@@ -562,6 +564,37 @@ class GaussLogpFn(torch.autograd.Function):
         L.call("rfn_gauss_logp_bwd_f32", zp, _l(zns), op, _l(ons), L.dev(g.contiguous()), gzp, _l(gzns), gop, _l(gons),
                _i(layout), _i(std_mode), _i(N), _i(Cz), _i(_hw(z)))
         return gz, go, None, None
+
+
+class LatentStepFn(torch.autograd.Function):
+    """one SRNN latent step (RFN_new.py:167-184,206-207): from the raw outputs of the encoder / prior parameter convs
+    to (z_t, z^x_t, KL, enc_mean, enc_std) in one kernel each way (rfn_latent_step_{fwd,bwd}_f32)."""
+
+    @staticmethod
+    def forward(ctx, enc, pri, eps_p, eps_q, res_q):
+        B = int(enc.shape[0])
+        shp = (B, enc.shape[1] // 2) + tuple(enc.shape[2:])
+        ZHW = 1
+        for d in shp[1:]:
+            ZHW *= int(d)
+        enc, pri, eps_p, eps_q = enc.contiguous(), pri.contiguous(), eps_p.contiguous(), eps_q.contiguous()
+        outs = [torch.empty(shp, device=enc.device, dtype=torch.float32) for _ in range(5)]
+        L.call("rfn_latent_step_fwd_f32", L.dev(enc), L.dev(pri), L.dev(eps_p), L.dev(eps_q), *[L.dev(o) for o in outs],
+               _i(B), _i(ZHW), _i(1 if res_q else 0))
+        ctx.save_for_backward(enc, pri, eps_p, eps_q)
+        ctx.cfg = (B, ZHW, bool(res_q))
+        return tuple(outs)
+
+    @staticmethod
+    def backward(ctx, g_zt, g_zxt, g_kl, g_em, g_es):
+        enc, pri, eps_p, eps_q = ctx.saved_tensors
+        B, ZHW, res_q = ctx.cfg
+        # keep the contiguous copies alive until the launch is enqueued (a freed temporary's block would be reused)
+        gs = [None if g is None else g.contiguous() for g in (g_zt, g_zxt, g_kl, g_em, g_es)]
+        g_enc, g_pri = torch.empty_like(enc), torch.empty_like(pri)
+        L.call("rfn_latent_step_bwd_f32", L.dev(enc), L.dev(pri), L.dev(eps_p), L.dev(eps_q), *[L.dev(g) for g in gs],
+               L.dev(g_enc), L.dev(g_pri), _i(B), _i(ZHW), _i(1 if res_q else 0))
+        return g_enc, g_pri, None, None, None
 
 
 class ConvLSTMCellFn(torch.autograd.Function):

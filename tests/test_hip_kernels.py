@@ -216,6 +216,39 @@ def test_gauss_logp_fwd_bwd_sample(K, layout, std_mode):
     assert relerr(zs, (mean + std * 0.7 * eps)) < 1e-5
 
 
+@pytest.mark.parametrize("res_q", [False, True])
+@pytest.mark.parametrize("use", ["all", "kl_only", "no_kl"])
+def test_latent_step_fwd_bwd(K, res_q, use):
+    """rfn_latent_step_*: chunk + softplus + res_q shift + both rsamples + KL of RFN.loss's per-step glue
+    (RFN_new.py:167-184,206-207) against the oracle's torch.distributions formulation, values and gradients."""
+    import torch.distributions as td
+    g = torch.Generator().manual_seed(60)
+    B, Z, H, W = 3, 7, 2, 2
+    enc = (torch.randn(B, 2 * Z, H, W, generator=g) * 1.5).requires_grad_(True)
+    pri = (torch.randn(B, 2 * Z, H, W, generator=g) * 1.5).requires_grad_(True)
+    with torch.no_grad():
+        enc[0, Z, 0, 0] = 25.0  # softplus threshold branch
+        pri[1, Z + 1, 1, 0] = 30.0
+    ep, eq = torch.randn(B, Z, H, W, generator=g), torch.randn(B, Z, H, W, generator=g)
+    em, eraw = enc.chunk(2, 1)
+    pm, praw = pri.chunk(2, 1)
+    es, ps = F.softplus(eraw), F.softplus(praw)
+    if res_q:
+        em = pm + em
+    refs = [pm + ps * ep, em + es * eq, td.kl_divergence(td.Normal(em, es), td.Normal(pm, ps)), em, es]
+    gouts = [torch.randn(B, Z, H, W, generator=g) for _ in range(5)]
+    sel = {"all": [0, 1, 2, 3, 4], "kl_only": [2], "no_kl": [0, 1, 3, 4]}[use]
+    sum((refs[i] * gouts[i]).sum() for i in sel).backward()
+    ek, pk = cu(enc.detach()).requires_grad_(True), cu(pri.detach()).requires_grad_(True)
+    outs = K.LatentStepFn.apply(ek, pk, cu(ep), cu(eq), res_q)
+    for o, r in zip(outs, refs):
+        assert relerr(o, r) < 1e-5
+    # non-contiguous incoming gradients (as the slices of a cat's gradient are in RFN.loss)
+    sum((outs[i] * cu(gouts[i].repeat_interleave(2, dim=-1))[..., ::2]).sum() for i in sel).backward()
+    assert relerr(ek.grad, enc.grad) < 1e-5
+    assert relerr(pk.grad, pri.grad) < 1e-5
+
+
 @pytest.mark.parametrize("N,Cin,C,H,W", [(3, 40, 4, 8, 8), (2, 256, 8, 16, 16), (5, 24, 2, 3, 5)])
 def test_tap_expanded_zeros_conv_fwd_wgrad(K, N, Cin, C, H, W):
     """Conv2dZeros with tiny Cout: 1x1 conv to 9C channels + tap gather == the 3x3 conv; scatter + 1x1 wgrad == wgrad"""

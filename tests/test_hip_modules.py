@@ -327,6 +327,50 @@ def test_graph_captured_step_equals_eager_step():
                                        msg=lambda m: n + ": " + m)
 
 
+def test_graph_replays_are_reproducible_canonical_architecture():
+    """canonical architecture (split-K / few-pixel kernels, multi-block torch reductions) at B=2, T=4 with pinned draws
+    and lr=0: every replay of the captured step must reproduce the eager loss and gradients.  Guards the ROCm graph
+    memset-node race (rfn_hip/__init__.py): with it, replays sporadically return stale / non-finite values."""
+    import main_rfn
+    from RFN.trainer import Solver
+    from RFN import RFN
+    from rfn_hip import dist as rdist
+    B, T = 2, 4
+    args = main_rfn.build_parser().parse_args(main_rfn.canonical_smmnist_argv(B, T))
+    args.path = "/gpurun_out/tmp/"
+    args.beta_min = args.beta_max = 0.5
+    torch.manual_seed(5)
+    s = Solver(args)
+    s.device = torch.device("cuda")
+    s.model = RFN(args).cuda().train()
+    s.reducer = rdist.GradBucketReducer(list(s.model.named_parameters()))
+    s.optimizer = torch.optim.SGD(s.model.parameters(), lr=0.0)
+    g = torch.Generator().manual_seed(6)
+    x = torch.rand(B, T, 1, 64, 64, generator=g).cuda()
+    zshape = tuple(s.model.z_0.shape)
+    draws = []
+    for _ in range(T - 1):
+        draws += [torch.randn(zshape, generator=g).cuda(), torch.randn(zshape, generator=g).cuda(),
+                  (torch.rand(B, 1, 64, 64, generator=g) / 256).cuda()]
+    s.model.loss(s.preprocess(x), 0, draws=draws)  # data dependent init
+    kl_fb, kl, nll = s.model.loss(s.preprocess(x), 0, draws=draws)
+    s.optimizer.zero_grad(set_to_none=True)
+    (nll + 0.5 * kl_fb).backward()
+    eager = {n: p.grad.detach().clone() for n, p in s.model.named_parameters() if p.grad is not None}
+    eager_loss = float(nll + 0.5 * kl_fb)
+    del kl_fb, kl, nll
+    s.optimizer.zero_grad(set_to_none=True)
+    assert s.capture_graph(x, static_draws=draws), getattr(s, "_graph_error", "")
+    for r in range(8):
+        out = s.train_step(x)
+        torch.cuda.synchronize()
+        assert abs(float(out) - eager_loss) <= 2e-5 * abs(eager_loss), (r, float(out), eager_loss)
+        for n, p in s.model.named_parameters():
+            if n in eager:
+                torch.testing.assert_close(p.grad, eager[n], rtol=1e-3, atol=2e-4 * float(eager[n].abs().max()) + 1e-7,
+                                           msg=lambda m: "replay %d %s: %s" % (r, n, m))
+
+
 def test_glowstep_hd64_gradients_vs_oracle(conv_precision):
     """hidden width 64 takes the fused data-gradient + activation-backward kernels (the golden fixtures use 16)."""
     from Flow import GlowStep
