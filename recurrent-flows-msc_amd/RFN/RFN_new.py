@@ -165,13 +165,14 @@ class RFN(nn.Module):
         base_t, noise_t = [], []
         # all 2(T-1) reparameterisation draws of the loop in one launch
         eps_all = None if draws is not None else torch.randn((T - 1, 2) + tuple(zprev.shape), device=dev)
+        enc_net, pri_net = self.encoder.recurrent(), self.prior.recurrent()  # weight gradients time-batched
         for i in range(1, T):
             ht = store_ht[i - 1]
             if self.enable_smoothing:
-                enc_raw = self.encoder.raw(torch.cat((store_at[i - 1], zxprev), dim=1))
+                enc_raw = enc_net(torch.cat((store_at[i - 1], zxprev), dim=1))
             else:
-                enc_raw = self.encoder.raw(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
-            pri_raw = self.prior.raw(torch.cat((ht, zxprev if self.res_q else zprev), dim=1))
+                enc_raw = enc_net(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
+            pri_raw = pri_net(torch.cat((ht, zxprev if self.res_q else zprev), dim=1))
             # chunk + softplus, res_q shift, both reparameterised draws and the KL in one kernel (RNG order: prior first)
             eps_p = eps_like(zprev) if eps_all is None else eps_all[i - 1, 0]
             eps_q = eps_like(zprev) if eps_all is None else eps_all[i - 1, 1]

@@ -7,6 +7,7 @@
 """
 import torch
 import torch.nn as nn
+import torch.nn.functional as F
 
 from rfn_hip import ops as K
 
@@ -277,6 +278,68 @@ class VGG_upscaler(nn.Module):
         return outputs
 
 
+class _StepStash:
+    """inputs / pre-activation gradients of one conv layer collected over the timesteps of a recurrence"""
+
+    def __init__(self):
+        self.xs, self.gs = [], []
+
+
+class _WeightPort(torch.autograd.Function):
+    """Entry of a conv layer's (weight, bias) into a recurrence that applies the layer once per timestep.  The per-step
+    functions (_StepConvAct) return no weight gradient; autograd runs this node's backward after all of them, and it
+    computes the weight and bias gradients of ALL steps as one convolution-backward over the time-batched stash — one
+    launch sequence and one accumulation into .grad instead of one per timestep."""
+
+    @staticmethod
+    def forward(ctx, w, b, stash):
+        ctx.set_materialize_grads(False)
+        ctx.stash = stash
+        ctx.save_for_backward(w)
+        return w.view_as(w), b.view_as(b)
+
+    @staticmethod
+    def backward(ctx, _gw, _gb):
+        (w,) = ctx.saved_tensors
+        st = ctx.stash
+        if not st.gs:
+            return None, None, None
+        X, G = torch.cat(st.xs, 0), torch.cat(st.gs, 0)
+        st.xs, st.gs = [], []
+        _, gw, gb = torch.ops.aten.convolution_backward(G, X, w, [w.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                        [False, True, True])
+        return gw, gb, None
+
+
+class _StepConvAct(torch.autograd.Function):
+    """one timestep of conv3x3(pad 1) + bias [+ leaky_relu]; backward = activation backward + data gradient only,
+    the weight gradient is deferred to _WeightPort."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stash, slope):
+        y = F.conv2d(x, w, b, padding=1)
+        if slope is not None:
+            F.leaky_relu_(y, slope)
+        ctx.stash, ctx.slope = stash, slope
+        ctx.save_for_backward(x, w, y if slope is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, w, y = ctx.saved_tensors
+        if ctx.slope is not None:
+            g = torch.ops.aten.leaky_relu_backward(g, y, ctx.slope, True)
+        else:
+            g = g.contiguous()
+        ctx.stash.xs.append(x)
+        ctx.stash.gs.append(g)
+        gx = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(g, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        return gx, None, None, None, None
+
+
 class SimpleParamNet(nn.Module):
     """Utils/modules.py:216-244 — conv stack then a conv producing (loc, softplus(raw scale))."""
 
@@ -302,6 +365,37 @@ class SimpleParamNet(nn.Module):
     def raw(self, x):
         """[B, 2*out, h, w] = (loc | raw scale) before the chunk + softplus of forward()."""
         return self.param_net(self.net(x))
+
+    def recurrent(self, force=False):
+        """A callable equal to `raw` for use once per timestep inside ONE loss evaluation: the weight / bias gradients
+        of all its calls are computed time-batched when the backward pass leaves the recurrence (_WeightPort).  Falls
+        back to `raw` for layer stacks other than [conv3x3 s1, no norm, leaky_relu / relu-free]* (e.g. batchnorm)."""
+        layers = list(self.net)
+        ok = torch.is_grad_enabled() and len(layers) % 3 == 0 and (self.param_net.weight.is_cuda or force)
+        convs = []
+        for i in range(0, len(layers), 3):
+            if not ok:
+                break
+            c, n, a = layers[i:i + 3]
+            ok = (isinstance(c, nn.Conv2d) and c.kernel_size == (3, 3) and c.stride == (1, 1) and c.padding == (1, 1)
+                  and isinstance(n, NormLayer) and isinstance(n.norm, NoNorm) and isinstance(a, ActFun)
+                  and isinstance(a.net, nn.LeakyReLU))
+            if ok:
+                convs.append((c, a.net.negative_slope))
+        if not ok:
+            return self.raw
+        convs.append((self.param_net, None))
+        ports = []
+        for c, slope in convs:
+            st = _StepStash()
+            w, b = _WeightPort.apply(c.weight, c.bias, st)
+            ports.append((w, b, st, slope))
+
+        def run(x):
+            for w, b, st, slope in ports:
+                x = _StepConvAct.apply(x, w, b, st, slope)
+            return x
+        return run
 
     def forward(self, x):
         loc, log_scale = self.raw(x).chunk(2, 1)

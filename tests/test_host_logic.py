@@ -210,3 +210,35 @@ def test_per_step_batchnorm_equals_sequential_calls():
     torch.testing.assert_close(bn_b.running_mean, bn_a.running_mean, rtol=1e-5, atol=1e-6)
     torch.testing.assert_close(bn_b.running_var, bn_a.running_var, rtol=1e-5, atol=1e-6)
     assert int(bn_b.num_batches_tracked) == int(bn_a.num_batches_tracked) == S
+
+
+def test_recurrent_param_net_deferred_weight_gradients():
+    """SimpleParamNet.recurrent(): per-step calls whose weight gradients are computed once, time-batched, must give the
+    same outputs and gradients as calling the module every step (RFN_new.py:167-179 calls prior/encoder per timestep)."""
+    import copy
+    from Utils.modules import SimpleParamNet
+    torch.manual_seed(0)
+    net = SimpleParamNet([12, 10], in_channels=7, out_channels=3, norm_type="none", non_lin="leakyrelu").double()
+    ref = copy.deepcopy(net)
+    x0 = torch.randn(2, 4, 2, 2, dtype=torch.double, requires_grad=True)
+    x1 = x0.detach().clone().requires_grad_(True)
+    h = [torch.randn(2, 3, 2, 2, dtype=torch.double) for _ in range(5)]
+
+    def roll(call, x):
+        out, z = 0, x
+        for t in range(5):
+            r = call(torch.cat((z, h[t]), 1))
+            out = out + (r * (t + 1)).sum()
+            z = torch.tanh(r[:, :4])
+        return out
+    f = net.recurrent(force=True)
+    assert f != net.raw
+    a, b = roll(f, x0), roll(ref.raw, x1)
+    assert torch.allclose(a, b, rtol=1e-12)
+    a.backward(); b.backward()
+    assert torch.allclose(x0.grad, x1.grad, rtol=1e-10, atol=1e-12)
+    for (n, p), (_, q) in zip(net.named_parameters(), ref.named_parameters()):
+        assert torch.allclose(p.grad, q.grad, rtol=1e-10, atol=1e-12), n
+    # norm layers other than "none" keep the plain path
+    bn = SimpleParamNet([8], in_channels=4, out_channels=2, norm_type="batchnorm")
+    assert bn.recurrent(force=True) == bn.raw
