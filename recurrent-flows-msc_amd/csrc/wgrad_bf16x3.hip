@@ -24,14 +24,19 @@ struct GemmWgradParams {
     int n_stages;
 };
 
+// WM x WN waves (4 or 8) of TM x TN 32x32 tiles each.  The 8-wave 256-row configurations read both operands of the
+// big level-0 / level-1 gradients exactly once (a 128 x 128 tiling of a 256 x 256 gradient reads each of them twice,
+// and those launches sit on the HBM roof).
 template <int WM, int WN, int TM, int TN, int KP>
-__global__ __launch_bounds__(256) void gemm_wgrad_b3_kernel(const GemmWgradParams p) {
+__global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmWgradParams p) {
+    constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     constexpr int NU = KP / 8;        // 16-byte units (8 pixels) per row and stage
     constexpr int RS = NU + 1;        // odd-ish row stride in units -> conflict-free b128 fragment reads
-    constexpr int AU = BM * NU / 256; // units staged per thread (A), BM*NU is a multiple of 256
-    constexpr int BU = BN * NU / 256;
-    static_assert(WM * WN == 4 && (BM * NU) % 256 == 0 && (BN * NU) % 256 == 0, "tile/stage shape");
+    constexpr int AU = (BM * NU + NT - 1) / NT;  // units staged per thread (A)
+    constexpr int BU = (BN * NU + NT - 1) / NT;
+    constexpr bool AX = (BM * NU) % NT == 0, BX = (BN * NU) % NT == 0;  // exact: no tail guard
+    static_assert(WM * WN == 4 || WM * WN == 8, "tile/stage shape");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     bf16x8* Ah = reinterpret_cast<bf16x8*>(lds_raw);
     bf16x8* Al = Ah + BM * RS;
@@ -50,7 +55,7 @@ __global__ __launch_bounds__(256) void gemm_wgrad_b3_kernel(const GemmWgradParam
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // staging: unit e = tid + 256*u  ->  row = e / NU, k-group = e % NU   (consecutive threads = consecutive pixels)
+    // staging: unit e = tid + NT*u  ->  row = e / NU, k-group = e % NU   (consecutive threads = consecutive pixels)
     float4 ast[AU][2], bst[BU][2];
     auto load8 = [&](const float* base, long ns, int rows, int row, long q0, float4 (&dst)[2]) {
         // two 4-pixel groups; a group never straddles a frame because HW % 4 == 0
@@ -69,13 +74,13 @@ __global__ __launch_bounds__(256) void gemm_wgrad_b3_kernel(const GemmWgradParam
         const long qs = (long)stage * KP;
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-            const int e = tid + 256 * u;
-            load8(p.a, p.a_ns, p.M, m0 + e / NU, qs + 8 * (e % NU), ast[u]);
+            const int e = tid + NT * u;
+            if (AX || e < BM * NU) load8(p.a, p.a_ns, p.M, m0 + e / NU, qs + 8 * (e % NU), ast[u]);
         }
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
-            const int e = tid + 256 * u;
-            load8(p.b, p.b_ns, p.N, n0 + e / NU, qs + 8 * (e % NU), bst[u]);
+            const int e = tid + NT * u;
+            if (BX || e < BN * NU) load8(p.b, p.b_ns, p.N, n0 + e / NU, qs + 8 * (e % NU), bst[u]);
         }
     };
     auto split_store = [&](const float4 (&src)[2], bf16x8* hi_p, bf16x8* lo_p) {
@@ -93,15 +98,15 @@ __global__ __launch_bounds__(256) void gemm_wgrad_b3_kernel(const GemmWgradParam
     auto commit = [&]() {
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-            const int e = tid + 256 * u;
+            const int e = tid + NT * u;
             const int o = (e / NU) * RS + e % NU;
-            split_store(ast[u], Ah + o, Al + o);
+            if (AX || e < BM * NU) split_store(ast[u], Ah + o, Al + o);
         }
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
-            const int e = tid + 256 * u;
+            const int e = tid + NT * u;
             const int o = (e / NU) * RS + e % NU;
-            split_store(bst[u], Bh + o, Bl + o);
+            if (BX || e < BN * NU) split_store(bst[u], Bh + o, Bl + o);
         }
     };
 
@@ -157,13 +162,13 @@ static void launch_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
     p.n_stages = (int)((p.total + KP - 1) / KP);
     size_t lds = (size_t)2 * (BM + BN) * (KP / 8 + 1) * 16;
     int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    int S = 1024 / tiles;
+    int S = (WM * WN == 8 ? 256 : 1024) / tiles;  // 8-wave tiles: one workgroup per CU
     if (S < 1) S = 1;
     if (S > p.n_stages) S = p.n_stages;
     auto kern = gemm_wgrad_b3_kernel<WM, WN, TM, TN, KP>;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
-    hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
 }
 
 extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw,
@@ -177,7 +182,13 @@ extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const flo
     p.a = a; p.b = b; p.a_ns = a_ns; p.b_ns = b_ns; p.M = M; p.N = Nc; p.gw = gw; p.F = F; p.HW = HW;
     p.total = (long)F * HW;
     hipStream_t s = (hipStream_t)stream;
-    if (M <= 64)
+    static const int variant = getenv("RFN_WGRAD_VARIANT") ? atoi(getenv("RFN_WGRAD_VARIANT")) : 0;
+    const bool big = variant != 1 && M > 128 && Nc > 128 && p.total >= 100000;
+    if (big && ceil_div(Nc, 192) * 192 < ceil_div(Nc, 256) * 256)
+        launch_gemm_wgrad<4, 2, 2, 3, 32>(p, s);   // 256 x 192, 8 waves
+    else if (big)
+        launch_gemm_wgrad<2, 4, 4, 2, 32>(p, s);   // 256 x 256, 8 waves
+    else if (M <= 64)
         launch_gemm_wgrad<1, 4, 2, 2, 32>(p, s);   // 64 x 256
     else if (Nc <= 64)
         launch_gemm_wgrad<4, 1, 2, 2, 32>(p, s);   // 256 x 64
@@ -209,10 +220,54 @@ __global__ void im2col3x3_kernel(const float* __restrict__ in1, long in1_ns, int
         out[idx] = v;
     }
 }
+// W % 4 == 0: one thread = 4 consecutive pixels of one (frame, tap*Cin+ci, y) row -> one 16-byte store, the index
+// divisions amortised over 4 elements (the element-wise kernel above spends its time in them).
+__global__ void im2col3x3_v4_kernel(const float* __restrict__ in1, long in1_ns, int C1, const float* __restrict__ in2,
+                                    long in2_ns, int C2, float* __restrict__ out, int N, int H, int W) {
+    const int Cin = C1 + C2, HW4 = H * W / 4, W4 = W / 4;
+    const long HW = (long)H * W, total = (long)N * 9 * Cin * HW4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % HW4);
+        const long r = idx / HW4;
+        const int tc = (int)(r % (9 * Cin));
+        const long n = r / (9 * Cin);
+        const int t = tc / Cin, ci = tc - t * Cin;
+        const int y = q / W4, x0 = (q - y * W4) * 4;
+        const int yy = y + t / 3 - 1, dx = t % 3 - 1;
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H) {
+            const float* src = (ci < C1 ? in1 + n * in1_ns + (long)ci * HW : in2 + n * in2_ns + (long)(ci - C1) * HW) +
+                               (long)yy * W;
+            if (dx == 0) {
+                v = *reinterpret_cast<const float4*>(src + x0);
+            } else {
+                const float4 c = *reinterpret_cast<const float4*>(src + x0);
+                if (dx < 0) {
+                    v.x = x0 > 0 ? src[x0 - 1] : 0.f;
+                    v.y = c.x; v.z = c.y; v.w = c.z;
+                } else {
+                    v.x = c.y; v.y = c.z; v.z = c.w;
+                    v.w = x0 + 4 < W ? src[x0 + 4] : 0.f;
+                }
+            }
+        }
+        *reinterpret_cast<float4*>(out + idx * 4) = v;
+    }
+}
 extern "C" int rfn_im2col3x3_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
                                  float* out, int N, int H, int W, rfn_stream_t stream) {
     RFN_CHECK_ARG(in1 && out && C1 > 0 && C2 >= 0 && (C2 == 0 || in2) && N >= 0 && H > 0 && W > 0, -1);
     if (N == 0) return 0;
+    hipStream_t s = (hipStream_t)stream;
+    const long HWl = (long)H * W;
+    if (W % 4 == 0 && in1_ns % 4 == 0 && (C2 == 0 || in2_ns % 4 == 0) && HWl % 4 == 0 &&
+        (((uintptr_t)in1 | (uintptr_t)out | (uintptr_t)(C2 ? in2 : in1)) & 15) == 0) {
+        long tot4 = (long)N * 9 * (C1 + C2) * (HWl / 4);
+        int grid4 = (int)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384);
+        hipLaunchKernelGGL(im2col3x3_v4_kernel, dim3(grid4), dim3(256), 0, s, in1, in1_ns, C1, in2, in2_ns, C2, out, N, H, W);
+        RFN_LAUNCH_CHECK();
+        return 0;
+    }
     long tot = (long)N * 9 * (C1 + C2) * H * W;
     int grid = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
     hipLaunchKernelGGL(im2col3x3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in1, in1_ns, C1, in2, in2_ns, C2,

@@ -226,6 +226,13 @@ def wgrad_kernel_name(Cout, Cin, ks, HW):
     return "wgrad_mfma_kernel<%d,%s,64>" % (ks, cfg)
 
 
+def _gemm_wgrad_cfg(M, Nc, total):
+    """mirror of the tile choice in rfn_gemm_wgrad_bf16x3 (csrc/wgrad_bf16x3.hip), for profiling labels only"""
+    if M > 128 and Nc > 128 and total >= 100000:
+        return "4,2,2,3,32" if -(-Nc // 192) * 192 < -(-Nc // 256) * 256 else "2,4,4,2,32"
+    return "1,4,2,2,32" if M <= 64 else ("4,1,2,2,32" if Nc <= 64 else "2,2,2,2,64")
+
+
 def gemm_wgrad(a, b, M, Nc, arena=None):
     """gw[M][Nc] = Σ_{frames,pixels} a[f,m,p] b[f,n,p] on the split-precision MFMA GEMM (rfn_gemm_wgrad_bf16x3)."""
     F_, HW = int(a.shape[0]), _hw(a)
@@ -233,8 +240,7 @@ def gemm_wgrad(a, b, M, Nc, arena=None):
     bp, bns = L.frames(b, "b")
     gw = _zeros(arena, M, Nc, device=a.device)
     L.call("rfn_gemm_wgrad_bf16x3", ap, _l(ans), _i(M), bp, _l(bns), _i(Nc), L.dev(gw), _i(F_), _i(HW),
-           meta=("wgrad", "gemm_wgrad_b3_kernel<%s>" % ("1,4,2,2,32" if M <= 64 else ("4,1,2,2,32" if Nc <= 64 else
-                                                                                        "2,2,2,2,64")),
+           meta=("wgrad", "gemm_wgrad_b3_kernel<%s>" % _gemm_wgrad_cfg(M, Nc, F_ * HW),
                  2.0 * F_ * HW * M * Nc, "F%d %dx%d HW%d" % (F_, M, Nc, HW), 4.0 * (F_ * HW * (M + Nc) + M * Nc)))
     return gw
 

@@ -216,6 +216,21 @@ def test_gauss_logp_fwd_bwd_sample(K, layout, std_mode):
     assert relerr(zs, (mean + std * 0.7 * eps)) < 1e-5
 
 
+@pytest.mark.parametrize("M,Nc,F_,H", [(256, 256, 100, 32), (256, 162, 100, 32), (200, 324, 400, 16), (256, 256, 3, 8)])
+def test_gemm_wgrad_tilings(K, M, Nc, F_, H):
+    """rfn_gemm_wgrad_bf16x3 on the 8-wave 256 x 256 / 256 x 192 tilings (taken for >= 100000 pixels) and the 128 x 128
+    one: gw[m][n] = sum over frames and pixels of a*b, against an fp64 einsum."""
+    if K.CONV_PRECISION != "bf16x3":
+        pytest.skip("split-precision GEMM only")
+    g = torch.Generator().manual_seed(70)
+    a = torch.randn(F_, M, H, H, generator=g)
+    b = torch.randn(F_, Nc, H, H, generator=g)
+    ref = torch.einsum("fmp,fnp->mn", a.flatten(2).double(), b.flatten(2).double())
+    gw = K.gemm_wgrad(cu(a), cu(b), M, Nc)
+    torch.cuda.synchronize()
+    assert relerr(gw, ref.float()) < 2e-5
+
+
 @pytest.mark.parametrize("res_q", [False, True])
 @pytest.mark.parametrize("use", ["all", "kl_only", "no_kl"])
 def test_latent_step_fwd_bwd(K, res_q, use):
