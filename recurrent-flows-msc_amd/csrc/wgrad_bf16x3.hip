@@ -57,30 +57,50 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 
     // staging: unit e = tid + NT*u  ->  row = e / NU, k-group = e % NU   (consecutive threads = consecutive pixels)
     float4 ast[AU][2], bst[BU][2];
-    auto load8 = [&](const float* base, long ns, int rows, int row, long q0, float4 (&dst)[2]) {
-        // two 4-pixel groups; a group never straddles a frame because HW % 4 == 0
+    // All units of a thread share the k-group (NT % NU == 0), so the (frame, pixel) split of a stage's two 4-pixel
+    // groups is computed once per stage and thread -- the only divisions of the loop (32-bit: total < 2^31 is checked
+    // on the host).  A group never straddles a frame because HW % 4 == 0.
+    static_assert(NT % NU == 0, "k-group must be a per-thread constant");
+    const int kg = tid % NU, r0 = tid / NU;   // unit u of this thread: row r0 + u*(NT/NU), k-group kg
+    const unsigned uHW = (unsigned)p.HW;
+    auto prefetch = [&](int stage) {
+        const unsigned q0 = (unsigned)stage * KP + 8u * kg;
+        long offa[2], offb[2];
+        bool okq[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
-            const long q = q0 + 4 * h;
-            const bool ok = row < rows && q < p.total;
-            const long qq = ok ? q : 0;
-            const long f = qq / p.HW;
-            const int px = (int)(qq - f * p.HW);
-            const float4 v = *reinterpret_cast<const float4*>(base + f * ns + (long)(ok ? row : 0) * p.HW + px);
-            dst[h] = ok ? v : float4{0.f, 0.f, 0.f, 0.f};
+            const unsigned q = q0 + 4u * h;
+            okq[h] = q < (unsigned)p.total;
+            const unsigned qq = okq[h] ? q : 0u;
+            const unsigned f = qq / uHW, px = qq - f * uHW;
+            offa[h] = (long)f * p.a_ns + px;
+            offb[h] = (long)f * p.b_ns + px;
         }
-    };
-    auto prefetch = [&](int stage) {
-        const long qs = (long)stage * KP;
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-            const int e = tid + NT * u;
-            if (AX || e < BM * NU) load8(p.a, p.a_ns, p.M, m0 + e / NU, qs + 8 * (e % NU), ast[u]);
+            const int row = m0 + r0 + u * (NT / NU);
+            if (AX || r0 + u * (NT / NU) < BM) {
+                const bool okr = row < p.M;
+                const float* base = p.a + (long)(okr ? row : 0) * p.HW;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + offa[h]);
+                    ast[u][h] = okr && okq[h] ? v : float4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
         }
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
-            const int e = tid + NT * u;
-            if (BX || e < BN * NU) load8(p.b, p.b_ns, p.N, n0 + e / NU, qs + 8 * (e % NU), bst[u]);
+            const int row = n0 + r0 + u * (NT / NU);
+            if (BX || r0 + u * (NT / NU) < BN) {
+                const bool okr = row < p.N;
+                const float* base = p.b + (long)(okr ? row : 0) * p.HW;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) {
+                    const float4 v = *reinterpret_cast<const float4*>(base + offb[h]);
+                    bst[u][h] = okr && okq[h] ? v : float4{0.f, 0.f, 0.f, 0.f};
+                }
+            }
         }
     };
     auto split_store = [&](const float4 (&src)[2], bf16x8* hi_p, bf16x8* lo_p) {
@@ -98,15 +118,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
     auto commit = [&]() {
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
-            const int e = tid + NT * u;
-            const int o = (e / NU) * RS + e % NU;
-            if (AX || e < BM * NU) split_store(ast[u], Ah + o, Al + o);
+            const int o = (r0 + u * (NT / NU)) * RS + kg;
+            if (AX || r0 + u * (NT / NU) < BM) split_store(ast[u], Ah + o, Al + o);
         }
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
-            const int e = tid + NT * u;
-            const int o = (e / NU) * RS + e % NU;
-            if (BX || e < BN * NU) split_store(bst[u], Bh + o, Bl + o);
+            const int o = (r0 + u * (NT / NU)) * RS + kg;
+            if (BX || r0 + u * (NT / NU) < BN) split_store(bst[u], Bh + o, Bl + o);
         }
     };
 
@@ -119,7 +137,8 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
         commit();
         __syncthreads();
         if (stage + (int)gridDim.x < p.n_stages) prefetch(stage + gridDim.x);
-#pragma unroll
+        // 8-wave tiles with 64-pixel stages: one k-step of fragments live at a time (register budget 256)
+#pragma unroll WM * WN == 8 && KP > 32 ? 1 : KP / 16
         for (int s = 0; s < KP / 16; ++s) {
             bf16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
@@ -176,6 +195,7 @@ extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const flo
     RFN_CHECK_ARG(a && b && gw && M > 0 && Nc > 0 && F >= 0 && HW > 0, -1);
     RFN_CHECK_ARG(HW % 4 == 0 && a_ns % 4 == 0 && b_ns % 4 == 0, -2);
     RFN_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0, -3);
+    RFN_CHECK_ARG((long)F * HW < (1L << 31) - 4096, -4);
     if (F == 0) return 0;
     GemmWgradParams p;
     memset(&p, 0, sizeof(p));
@@ -184,10 +204,15 @@ extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const flo
     hipStream_t s = (hipStream_t)stream;
     static const int variant = getenv("RFN_WGRAD_VARIANT") ? atoi(getenv("RFN_WGRAD_VARIANT")) : 0;
     const bool big = variant != 1 && M > 128 && Nc > 128 && p.total >= 100000;
-    if (big && ceil_div(Nc, 192) * 192 < ceil_div(Nc, 256) * 256)
-        launch_gemm_wgrad<4, 2, 2, 3, 32>(p, s);   // 256 x 192, 8 waves
+    if (big && ceil_div(Nc, 192) * 192 < ceil_div(Nc, 256) * 256) {
+        if (variant == 2)
+            launch_gemm_wgrad<4, 2, 2, 3, 32>(p, s);
+        else
+            launch_gemm_wgrad<4, 2, 2, 3, 64>(p, s);   // 256 x 192, 8 waves, 64-pixel stages
+    } else if (big && variant == 2)
+        launch_gemm_wgrad<2, 4, 4, 2, 32>(p, s);
     else if (big)
-        launch_gemm_wgrad<2, 4, 4, 2, 32>(p, s);   // 256 x 256, 8 waves
+        launch_gemm_wgrad<2, 4, 4, 2, 64>(p, s);   // 256 x 256, 8 waves, 64-pixel stages
     else if (M <= 64)
         launch_gemm_wgrad<1, 4, 2, 2, 32>(p, s);   // 64 x 256
     else if (Nc <= 64)

@@ -229,7 +229,7 @@ def wgrad_kernel_name(Cout, Cin, ks, HW):
 def _gemm_wgrad_cfg(M, Nc, total):
     """mirror of the tile choice in rfn_gemm_wgrad_bf16x3 (csrc/wgrad_bf16x3.hip), for profiling labels only"""
     if M > 128 and Nc > 128 and total >= 100000:
-        return "4,2,2,3,32" if -(-Nc // 192) * 192 < -(-Nc // 256) * 256 else "2,4,4,2,32"
+        return "4,2,2,3,64" if -(-Nc // 192) * 192 < -(-Nc // 256) * 256 else "2,4,4,2,64"
     return "1,4,2,2,32" if M <= 64 else ("4,1,2,2,32" if Nc <= 64 else "2,2,2,2,64")
 
 

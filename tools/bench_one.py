@@ -12,9 +12,18 @@ w = torch.randn(cout, cin, ks, ks, device="cuda") * 0.05
 g = torch.randn(N, cout, S, S, device="cuda")
 wp = K.pack_weight(w)
 out = torch.empty(N, cout, S, S, device="cuda")
-for _ in range(5):
+def run():
     if kind == "fwd":
         K.conv2d_raw(x, None, wp, cout, ks, out1=out)
     else:
         K.conv2d_wgrad(x, None, g, cout, ks)
+for _ in range(5):
+    run()
 torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(20):
+    run()
+e1.record()
+torch.cuda.synchronize()
+print("%s cin%d cout%d S%d k%d N%d: %.1f us per call" % (kind, cin, cout, S, ks, N, e0.elapsed_time(e1) / 20 * 1e3))
