@@ -63,14 +63,17 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
     static_assert(NT % NU == 0, "k-group must be a per-thread constant");
     const int kg = tid % NU, r0 = tid / NU;   // unit u of this thread: row r0 + u*(NT/NU), k-group kg
     const unsigned uHW = (unsigned)p.HW;
+    // The loads of the NEXT stage are issued ahead of the MFMAs of the current one and are not touched until the next
+    // commit: unconditional (clamped rows / pixels, no select on a loaded value, no control flow) -- otherwise the
+    // compiler waits for HBM right behind the loads and nothing overlaps.  Masks are applied in commit().
+    bool okq[2] = {false, false};
     auto prefetch = [&](int stage) {
         const unsigned q0 = (unsigned)stage * KP + 8u * kg;
         long offa[2], offb[2];
-        bool okq[2];
 #pragma unroll
         for (int h = 0; h < 2; ++h) {
             const unsigned q = q0 + 4u * h;
-            okq[h] = q < (unsigned)p.total;
+            okq[h] = stage < p.n_stages && q < (unsigned)p.total;
             const unsigned qq = okq[h] ? q : 0u;
             const unsigned f = qq / uHW, px = qq - f * uHW;
             offa[h] = (long)f * p.a_ns + px;
@@ -79,38 +82,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int row = m0 + r0 + u * (NT / NU);
-            if (AX || r0 + u * (NT / NU) < BM) {
-                const bool okr = row < p.M;
-                const float* base = p.a + (long)(okr ? row : 0) * p.HW;
+            const float* base = p.a + (long)(row < p.M ? row : 0) * p.HW;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float4 v = *reinterpret_cast<const float4*>(base + offa[h]);
-                    ast[u][h] = okr && okq[h] ? v : float4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
+            for (int h = 0; h < 2; ++h) ast[u][h] = *reinterpret_cast<const float4*>(base + offa[h]);
         }
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
             const int row = n0 + r0 + u * (NT / NU);
-            if (BX || r0 + u * (NT / NU) < BN) {
-                const bool okr = row < p.N;
-                const float* base = p.b + (long)(okr ? row : 0) * p.HW;
+            const float* base = p.b + (long)(row < p.N ? row : 0) * p.HW;
 #pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const float4 v = *reinterpret_cast<const float4*>(base + offb[h]);
-                    bst[u][h] = okr && okq[h] ? v : float4{0.f, 0.f, 0.f, 0.f};
-                }
-            }
+            for (int h = 0; h < 2; ++h) bst[u][h] = *reinterpret_cast<const float4*>(base + offb[h]);
         }
     };
-    auto split_store = [&](const float4 (&src)[2], bf16x8* hi_p, bf16x8* lo_p) {
+    auto split_store = [&](const float4 (&src)[2], bool okr, bf16x8* hi_p, bf16x8* lo_p) {
         const float v[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
         bf16x8 hi, lo;
 #pragma unroll
         for (int c = 0; c < 8; ++c) {
-            const __bf16 h = (__bf16)v[c];
+            const float x = (okr && okq[c >> 2]) ? v[c] : 0.f;
+            const __bf16 h = (__bf16)x;
             hi[c] = h;
-            lo[c] = (__bf16)(v[c] - (float)h);
+            lo[c] = (__bf16)(x - (float)h);
         }
         *hi_p = hi;
         *lo_p = lo;
@@ -119,24 +111,25 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int o = (r0 + u * (NT / NU)) * RS + kg;
-            if (AX || r0 + u * (NT / NU) < BM) split_store(ast[u], Ah + o, Al + o);
+            if (AX || r0 + u * (NT / NU) < BM) split_store(ast[u], m0 + r0 + u * (NT / NU) < p.M, Ah + o, Al + o);
         }
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
             const int o = (r0 + u * (NT / NU)) * RS + kg;
-            if (BX || r0 + u * (NT / NU) < BN) split_store(bst[u], Bh + o, Bl + o);
+            if (BX || r0 + u * (NT / NU) < BN) split_store(bst[u], n0 + r0 + u * (NT / NU) < p.N, Bh + o, Bl + o);
         }
     };
 
     const int arow = (wm * TM * 32 + l31) * RS + kk;  // + i*32*RS + 2*s
     const int brow = (wn * TN * 32 + l31) * RS + kk;
     int stage = blockIdx.x;
-    if (stage < p.n_stages) prefetch(stage);
+    prefetch(stage);
     for (; stage < p.n_stages; stage += gridDim.x) {
         __syncthreads();
         commit();
         __syncthreads();
-        if (stage + (int)gridDim.x < p.n_stages) prefetch(stage + gridDim.x);
+        prefetch(stage + gridDim.x);        // always issued; past the end it re-reads pixel 0 and is never committed
+        __builtin_amdgcn_sched_barrier(0);  // keep the loads ahead of the MFMAs (the scheduler sinks them)
         // 8-wave tiles with 64-pixel stages: one k-step of fragments live at a time (register budget 256)
 #pragma unroll WM * WN == 8 && KP > 32 ? 1 : KP / 16
         for (int s = 0; s < KP / 16; ++s) {

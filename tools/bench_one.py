@@ -5,6 +5,9 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "recurrent-flows-msc_amd"))
 import torch
 from rfn_hip import ops as K
+from rfn_hip import lib as _L
+if os.environ.get('RFN_LIB'):
+    _L.LIB_PATH = os.path.join(ROOT, os.environ['RFN_LIB'])
 kind, cin, cout, S, ks = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), int(sys.argv[4]), int(sys.argv[5])
 N = int(sys.argv[6]) if len(sys.argv) > 6 else 608
 x = torch.randn(N, cin, S, S, device="cuda")
