@@ -340,6 +340,32 @@ class _StepConvAct(torch.autograd.Function):
         return gx, None, None, None, None
 
 
+class _StepDenseAct(torch.autograd.Function):
+    """_StepConvAct on a small map (H*W <= 16) through the dense split-precision kernels (rfn_smallmap_dense_bf16x3):
+    one launch forward (bias + leaky_relu fused), one launch backward (leaky_relu backward fused, pre-activation
+    gradient written out for the deferred weight gradient)."""
+
+    @staticmethod
+    def forward(ctx, x, w, b, stash, slope, packs):
+        x = x.contiguous()
+        y = K.smallmap_dense(x, packs[0], int(w.shape[0]), bias=b, slope_out=slope)
+        ctx.stash, ctx.slope, ctx.packs, ctx.cin = stash, slope, packs, int(w.shape[1])
+        ctx.save_for_backward(x, y if slope is not None else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        x, y = ctx.saved_tensors
+        g = g.contiguous()
+        if ctx.slope is not None:
+            gx, gpre = K.smallmap_dense(g, ctx.packs[1], ctx.cin, y=y, slope_in=ctx.slope, want_a_out=True)
+        else:
+            gx, gpre = K.smallmap_dense(g, ctx.packs[1], ctx.cin), g
+        ctx.stash.xs.append(x)
+        ctx.stash.gs.append(gpre)
+        return gx, None, None, None, None, None
+
+
 class SimpleParamNet(nn.Module):
     """Utils/modules.py:216-244 — conv stack then a conv producing (loc, softplus(raw scale))."""
 
@@ -391,9 +417,19 @@ class SimpleParamNet(nn.Module):
             w, b = _WeightPort.apply(c.weight, c.bias, st)
             ports.append((w, b, st, slope))
 
+        packs = {}
+
         def run(x):
-            for w, b, st, slope in ports:
-                x = _StepConvAct.apply(x, w, b, st, slope)
+            H, W = int(x.shape[2]), int(x.shape[3])
+            dense = x.is_cuda and all(K.smallmap_supported(c, H, W) for c, _ in convs)
+            if dense and (H, W) not in packs:  # once per loss evaluation: both products of every layer
+                packs[(H, W)] = [(K.smallmap_pack(c.weight, H, W, False), K.smallmap_pack(c.weight, H, W, True))
+                                 for c, _ in convs]
+            for i, (w, b, st, slope) in enumerate(ports):
+                if dense:
+                    x = _StepDenseAct.apply(x, w, b, st, slope, packs[(H, W)][i])
+                else:
+                    x = _StepConvAct.apply(x, w, b, st, slope)
             return x
         return run
 

@@ -1,0 +1,176 @@
+// 3x3 convolutions on very small feature maps (H*W <= 16), batch-of-timestep sized: the per-timestep parameter nets of
+// the SRNN (RFN/RFN_new.py:167-179 call prior / encoder once per frame on [B, C, 2, 2] maps at 64x64 input).
+//
+// On a 2x2 (or 4x4) map with padding 1 every output pixel sees every input pixel, so the convolution IS a dense layer
+//     out[b][(co,po)] = bias[co] + sum_{(ci,pi)} x[b][(ci,pi)] * Weff[(ci,pi)][(co,po)],   Weff = w[co][ci][tap(po,pi)]
+// and (ci,pi) / (co,po) are exactly the NCHW memory order of one sample.  With B <= 32 samples the batch is ONE MFMA
+// row tile; the work is streaming Weff (a few MB, L2 / Infinity-Cache resident across the 19 timesteps) through the
+// matrix cores.  Weff is packed once per optimizer step in MFMA B-fragment order, already split into bf16 (hi, lo)
+// (split precision as in conv_bf16x3.hip: a*b ~= ah*bh + ah*bl + al*bh, fp32 accumulate), for the forward product and
+// transposed for the data gradient; the per-timestep kernels then issue one coalesced 16-byte load per fragment.
+// A general-purpose conv library pays ~35 us per such call (layout transposes + a tiled kernel + bias + activation
+// launches); these kernels are bound by the weight stream.
+#include "conv_common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+// ------------------------------------------------------------------------------------------------ packing
+// packed[((tile*KS + ks)*2 + plane)*64 + lane] (16-byte units): lane -> n = tile*32 + lane%32, k = ks*16 + (lane/32)*8 + j
+// transpose = 0: k = (ci,pi), n = (co,po)   (forward)        transpose = 1: k = (co,po), n = (ci,pi)   (data gradient)
+__global__ void smallmap_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int H, int W, int transpose,
+                                     bf16x8* __restrict__ packed, int KS, int NTILES) {
+    const int HW = H * W;
+    const long total = (long)NTILES * KS * 64;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(idx & 63);
+        const long r = idx >> 6;
+        const int ks = (int)(r % KS), tile = (int)(r / KS);
+        const int n = tile * 32 + (lane & 31);
+        const int kbase = ks * 16 + (lane >> 5) * 8;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int k = kbase + j;
+            const int cn = n / HW, pn = n - cn * HW, ck = k / HW, pk = k - ck * HW;
+            const int co = transpose ? ck : cn, po = transpose ? pk : pn;
+            const int ci = transpose ? cn : ck, pi = transpose ? pn : pk;
+            const int dy = pi / W - po / W + 1, dx = pi % W - po % W + 1;
+            float v = 0.f;
+            if (co < Cout && ci < Cin && dy >= 0 && dy < 3 && dx >= 0 && dx < 3)
+                v = w[((long)co * Cin + ci) * 9 + dy * 3 + dx];
+            const __bf16 h = (__bf16)v;
+            hi[j] = h;
+            lo[j] = (__bf16)(v - (float)h);
+        }
+        packed[(r * 2 + 0) * 64 + lane] = hi;
+        packed[(r * 2 + 1) * 64 + lane] = lo;
+    }
+}
+
+static void smallmap_dims(int Cout, int Cin, int HW, int transpose, int* K, int* N, int* KS, int* NTILES) {
+    *K = (transpose ? Cout : Cin) * HW;
+    *N = (transpose ? Cin : Cout) * HW;
+    *KS = (*K + 15) / 16;
+    *NTILES = (*N + 31) / 32;
+}
+
+extern "C" long rfn_smallmap_packed_size(int Cout, int Cin, int H, int W, int transpose) {
+    int K, N, KS, NT;
+    smallmap_dims(Cout, Cin, H * W, transpose, &K, &N, &KS, &NT);
+    return (long)NT * KS * 2 * 64 * 16;
+}
+
+extern "C" int rfn_smallmap_pack_bf16x3(const float* w, int Cout, int Cin, int H, int W, int transpose, float* packed,
+                                        rfn_stream_t stream) {
+    RFN_CHECK_ARG(w && packed && Cout > 0 && Cin > 0 && H > 0 && W > 0 && H * W <= 16, -1);
+    RFN_CHECK_ARG(((uintptr_t)packed & 15) == 0, -2);
+    int K, N, KS, NT;
+    smallmap_dims(Cout, Cin, H * W, transpose, &K, &N, &KS, &NT);
+    const long total = (long)NT * KS * 64;
+    const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
+    hipLaunchKernelGGL(smallmap_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, H, W, transpose,
+                       reinterpret_cast<bf16x8*>(packed), KS, NT);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ dense product
+struct SmallmapParams {
+    const float* a;       // [B][K]  (K = C*HW, one sample per row)
+    const float* y;       // optional [B][K]: a is scaled by (y > 0 ? 1 : slope_in) -- the backward of an in-place leaky_relu
+    float slope_in;
+    const bf16x8* packed;
+    const float* bias;    // optional, per output channel (n / HW)
+    int act_out;          // 1: leaky_relu(slope_out) on the output
+    float slope_out;
+    float* out;           // [B][N]
+    float* a_out;         // optional [B][K]: the scaled a (pre-activation gradient, kept for the weight gradient)
+    int B, K, N, HW, KS;
+};
+
+constexpr int SM_WAVES = 8;
+
+__global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const SmallmapParams p) {
+    __shared__ float red[SM_WAVES][32][33];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int l31 = lane & 31, kg = lane >> 5;
+    const int tile = blockIdx.x, m0 = blockIdx.y * 32;
+    const int m = m0 + l31;
+    const bool mok = m < p.B;
+    const float* arow = p.a + (long)(mok ? m : 0) * p.K;
+    const float* yrow = p.y ? p.y + (long)(mok ? m : 0) * p.K : nullptr;
+    float* aorow = (p.a_out && tile == 0 && mok) ? p.a_out + (long)m * p.K : nullptr;
+    const bf16x8* wp = p.packed + (long)tile * p.KS * 2 * 64 + lane;
+
+    f32x16 acc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+
+    for (int ks = wave; ks < p.KS; ks += SM_WAVES) {
+        const int k = ks * 16 + kg * 8;
+        const bool kok = mok && k < p.K;  // K % 8 == 0 (checked on the host): a group is all in or all out
+        const float* ap = arow + (kok ? k : 0);
+        float4 v0 = *reinterpret_cast<const float4*>(ap);
+        float4 v1 = *reinterpret_cast<const float4*>(ap + 4);
+        const bf16x8 bh = wp[(long)(ks * 2 + 0) * 64];
+        const bf16x8 bl = wp[(long)(ks * 2 + 1) * 64];
+        float v[8] = {v0.x, v0.y, v0.z, v0.w, v1.x, v1.y, v1.z, v1.w};
+        if (yrow) {
+            const float* yp = yrow + (kok ? k : 0);
+            const float4 y0 = *reinterpret_cast<const float4*>(yp);
+            const float4 y1 = *reinterpret_cast<const float4*>(yp + 4);
+            const float yy[8] = {y0.x, y0.y, y0.z, y0.w, y1.x, y1.y, y1.z, y1.w};
+#pragma unroll
+            for (int j = 0; j < 8; ++j) v[j] *= yy[j] > 0.f ? 1.f : p.slope_in;
+        }
+        if (aorow && kok) {
+            *reinterpret_cast<float4*>(aorow + k) = float4{v[0], v[1], v[2], v[3]};
+            *reinterpret_cast<float4*>(aorow + k + 4) = float4{v[4], v[5], v[6], v[7]};
+        }
+        bf16x8 ah, al;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const float x = kok ? v[j] : 0.f;
+            const __bf16 h = (__bf16)x;
+            ah[j] = h;
+            al[j] = (__bf16)(x - (float)h);
+        }
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al, bh, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bl, acc, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc, 0, 0, 0);
+    }
+    // D[row = batch][col = n]: register r of lane l holds row (r&3) + 8*(r>>2) + 4*(l/32), col l%32
+#pragma unroll
+    for (int r = 0; r < 16; ++r) red[wave][(r & 3) + 8 * (r >> 2) + 4 * kg][l31] = acc[r];
+    __syncthreads();
+    for (int idx = tid; idx < 32 * 32; idx += 64 * SM_WAVES) {
+        const int mm = idx >> 5, nn = idx & 31;
+        float s = 0.f;
+#pragma unroll
+        for (int w = 0; w < SM_WAVES; ++w) s += red[w][mm][nn];
+        const int n = tile * 32 + nn, row = m0 + mm;
+        if (row < p.B && n < p.N) {
+            if (p.bias) s += p.bias[n / p.HW];
+            if (p.act_out) s = s > 0.f ? s : s * p.slope_out;
+            p.out[(long)row * p.N + n] = s;
+        }
+    }
+}
+
+extern "C" int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float slope_in, const float* packed,
+                                         const float* bias, int act_out, float slope_out, float* out, float* a_out, int B,
+                                         int K, int N, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(a && packed && out && B >= 0 && K > 0 && N > 0 && HW > 0 && HW <= 16, -1);
+    RFN_CHECK_ARG(K % 8 == 0 && K % HW == 0 && N % HW == 0, -2);
+    RFN_CHECK_ARG((((uintptr_t)a | (uintptr_t)packed | (uintptr_t)(y ? y : a) | (uintptr_t)(a_out ? a_out : a)) & 15) == 0, -3);
+    if (B == 0) return 0;
+    SmallmapParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = a; p.y = y; p.slope_in = slope_in; p.packed = reinterpret_cast<const bf16x8*>(packed); p.bias = bias;
+    p.act_out = act_out; p.slope_out = slope_out; p.out = out; p.a_out = a_out;
+    p.B = B; p.K = K; p.N = N; p.HW = HW; p.KS = (K + 15) / 16;
+    dim3 grid((N + 31) / 32, (B + 31) / 32);
+    hipLaunchKernelGGL(smallmap_dense_kernel, grid, dim3(64 * SM_WAVES), 0, (hipStream_t)stream, p);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}

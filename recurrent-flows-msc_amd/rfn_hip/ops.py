@@ -572,6 +572,40 @@ class GaussLogpFn(torch.autograd.Function):
         return gz, go, None, None
 
 
+# ------------------------------------------------------------------------------------------------ small-map dense convs
+def smallmap_supported(conv, H, W):
+    """3x3 / stride 1 / pad 1 convolution on an H x W <= 16 map whose sample rows are 16-byte friendly"""
+    return (CONV_PRECISION == "bf16x3" and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+            and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
+            and conv.bias is not None and H * W <= 16 and (conv.in_channels * H * W) % 8 == 0
+            and (conv.out_channels * H * W) % 8 == 0)
+
+
+def smallmap_pack(w, H, W, transpose):
+    """w [Cout, Cin, 3, 3] -> MFMA-fragment-ordered bf16 (hi, lo) dense matrix of the H x W map (rfn_smallmap_pack_bf16x3)"""
+    Cout, Cin = int(w.shape[0]), int(w.shape[1])
+    nbytes = int(L.load().rfn_smallmap_packed_size(Cout, Cin, H, W, 1 if transpose else 0))
+    buf = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
+    wc = w.detach().contiguous()
+    L.call("rfn_smallmap_pack_bf16x3", L.dev(wc), _i(Cout), _i(Cin), _i(H), _i(W), _i(1 if transpose else 0), L.dev(buf))
+    return buf
+
+
+def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slope_in=0.0, want_a_out=False):
+    """out[B, n_channels, H, W] = a'[B, C, H, W] (as rows) x packed (+ bias, leaky_relu) -- rfn_smallmap_dense_bf16x3.
+    With y: a' = a * (y > 0 ? 1 : slope_in); returns (out, a') when want_a_out."""
+    a = a.contiguous()
+    B, H, W = int(a.shape[0]), int(a.shape[2]), int(a.shape[3])
+    K, HW = int(a.shape[1]) * H * W, H * W
+    out = torch.empty((B, n_channels, H, W), device=a.device, dtype=torch.float32)
+    a_out = torch.empty_like(a) if want_a_out else None
+    yc = None if y is None else y.contiguous()
+    L.call("rfn_smallmap_dense_bf16x3", L.dev(a), L.dev(yc), ctypes.c_float(slope_in), L.dev(packed), L.dev(bias),
+           _i(0 if slope_out is None else 1), ctypes.c_float(0.0 if slope_out is None else slope_out), L.dev(out),
+           L.dev(a_out), _i(B), _i(K), _i(n_channels * HW), _i(HW))
+    return (out, a_out) if want_a_out else out
+
+
 class LatentStepFn(torch.autograd.Function):
     """one SRNN latent step (RFN_new.py:167-184,206-207): from the raw outputs of the encoder / prior parameter convs
     to (z_t, z^x_t, KL, enc_mean, enc_std) in one kernel each way (rfn_latent_step_{fwd,bwd}_f32)."""

@@ -231,6 +231,35 @@ def test_gemm_wgrad_tilings(K, M, Nc, F_, H):
     assert relerr(gw, ref.float()) < 2e-5
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W", [(32, 768, 256, 2, 2), (4, 256, 112, 2, 2), (3, 10, 6, 4, 4), (40, 16, 8, 1, 2),
+                                             (5, 6, 10, 2, 4)])
+@pytest.mark.parametrize("slope", [0.2, None])
+def test_smallmap_dense_conv_fwd_bwd(K, B, Cin, Cout, H, W, slope):
+    """rfn_smallmap_{pack,dense}_bf16x3: conv3x3(pad 1) + bias [+ leaky_relu] on H*W <= 16 maps as one dense product,
+    and its backward (activation backward fused, data gradient through the transposed pack) -- the per-timestep
+    prior / encoder layers (Utils/modules.py:216-244 called from RFN_new.py:167-179) -- against F.conv2d autograd."""
+    if K.CONV_PRECISION != "bf16x3":
+        pytest.skip("split-precision kernels only")
+    g = torch.Generator().manual_seed(80)
+    x = torch.randn(B, Cin, H, W, generator=g, requires_grad=True)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) / (3 * Cin ** 0.5)).requires_grad_(True)
+    b = torch.randn(Cout, generator=g)
+    pre = F.conv2d(x, w, b, padding=1)
+    ref = F.leaky_relu(pre, slope) if slope is not None else pre
+    gout = torch.randn(B, Cout, H, W, generator=g)
+    ref.backward(gout)
+    gpre_ref = gout * ((pre > 0).float() + (pre <= 0).float() * slope) if slope is not None else gout
+    pf, pb = K.smallmap_pack(cu(w.detach()), H, W, False), K.smallmap_pack(cu(w.detach()), H, W, True)
+    y = K.smallmap_dense(cu(x.detach()), pf, Cout, bias=cu(b), slope_out=slope)
+    assert relerr(y, ref) < 2e-5
+    if slope is not None:
+        gx, gpre = K.smallmap_dense(cu(gout), pb, Cin, y=y, slope_in=slope, want_a_out=True)
+        assert relerr(gpre, gpre_ref) < 1e-6
+    else:
+        gx = K.smallmap_dense(cu(gout), pb, Cin)
+    assert relerr(gx, x.grad) < 2e-5
+
+
 @pytest.mark.parametrize("res_q", [False, True])
 @pytest.mark.parametrize("use", ["all", "kl_only", "no_kl"])
 def test_latent_step_fwd_bwd(K, res_q, use):
