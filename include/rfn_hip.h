@@ -197,14 +197,14 @@ int rfn_latent_step_bwd_f32(const float* enc, const float* pri, const float* eps
  * rfn_smallmap_pack_bf16x3 writes w [Cout][Cin][3][3] in MFMA fragment order, split into bf16 (hi, lo), for the forward
  * product (transpose 0: K = Cin*HW, N = Cout*HW) or the data gradient (transpose 1: K = Cout*HW, N = Cin*HW);
  * rfn_smallmap_packed_size gives the buffer size in bytes.  rfn_smallmap_dense_bf16x3: out[B][N] = a'[B][K] * packed
- * (+ bias[n / HW], then leaky_relu(slope_out) when act_out), where a' = a, or a * (y > 0 ? 1 : slope_in) when y is given
+ * (+ bias[n / HW] + add[B][N], each optional, then leaky_relu(slope_out) when act_out), where a' = a, or a * (y > 0 ? 1 : slope_in) when y is given
  * (backward of an in-place leaky_relu whose result is y); a_out (optional) receives a'.  K % 8 == 0. */
 long rfn_smallmap_packed_size(int Cout, int Cin, int H, int W, int transpose);
 int rfn_smallmap_pack_bf16x3(const float* w, int Cout, int Cin, int H, int W, int transpose, float* packed,
                              rfn_stream_t stream);
 int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float slope_in, const float* packed, const float* bias,
-                              int act_out, float slope_out, float* out, float* a_out, int B, int K, int N, int HW,
-                              rfn_stream_t stream);
+                              const float* add, int act_out, float slope_out, float* out, float* a_out, int B, int K, int N,
+                              int HW, rfn_stream_t stream);
 
 /* ---- a9  ConvLSTMLayer.forward gate update  (Utils/modules.py:370-377): cc = conv output [N,4*Hc,HW] in gate order
  * i,f,o,g;  i=σ(cc_i+Wci∘c) f=σ(cc_f+Wcf∘c) g=tanh(cc_g) c'=f∘c+i∘g o=σ(cc_o+Wco∘c') h'=o∘tanh(c').

@@ -120,16 +120,17 @@ class RFN(nn.Module):
 
     def _deterministic_states(self, feats, n_steps, hprev, cprev, aprev, caprev):
         """h_t for t = 1..n_steps-1 (RFN_new.py:131-139) and, with smoothing, the backward a_t (:142-153)."""
-        store_ht = []
-        for i in range(1, n_steps):
-            _, hprev, cprev = self.lstm(self._last(feats[i - 1]).unsqueeze(1), hprev, cprev)
-            store_ht.append(hprev)
+        if n_steps < 2:
+            return [], [], hprev, cprev
+        x_all = torch.stack([self._last(feats[i - 1]) for i in range(1, n_steps)], 0)  # frames 0..n-2, step-major
+        store_ht, hprev, cprev = self.lstm.forward_steps(x_all, hprev, cprev)
         store_at = [None] * (n_steps - 1)
-        if self.enable_smoothing:
+        if self.enable_smoothing:  # runs backward in time over (h_t, features of frame t+1)
+            inp = torch.stack([torch.cat([store_ht[n_steps - i - 1], self._last(feats[n_steps - i])], 1)
+                               for i in range(1, n_steps)], 0)
+            a_rev, aprev, caprev = self.a_lstm.forward_steps(inp, aprev, caprev)
             for i in range(1, n_steps):
-                inp = torch.cat([store_ht[n_steps - i - 1], self._last(feats[n_steps - i])], 1)
-                _, aprev, caprev = self.a_lstm(inp.unsqueeze(1), aprev, caprev)
-                store_at[n_steps - i - 1] = aprev
+                store_at[n_steps - i - 1] = a_rev[i - 1]
         return store_ht, store_at, hprev, cprev
 
     def _flow_needs_init(self):

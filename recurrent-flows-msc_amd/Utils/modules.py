@@ -473,6 +473,18 @@ class ConvLSTMLayer(nn.Module):
         self._pe_nonzero = None
         super()._load_from_state_dict(state_dict, prefix, *args, **kw)
 
+    def _peephole_tensors(self, h, w, device):
+        if not self.init_done:
+            self.initialize_peephole(h, w, device)
+            self.init_done = True
+        pe = [getattr(self, n, None) for n in ("Wci", "Wcf", "Wco")]
+        if pe[0] is not None:
+            if self._pe_nonzero is None:  # one host sync per (re)load, not per step; they are never trained
+                self._pe_nonzero = any(bool(t.any()) for t in pe)
+            if not self._pe_nonzero:
+                pe = [None, None, None]  # identically zero in every reference run: skip the reads
+        return pe
+
     def forward(self, input_tensor, cur_state):
         b, c, h, w = input_tensor.shape
         conv = self.conv[0]
@@ -481,15 +493,7 @@ class ConvLSTMLayer(nn.Module):
             c_cur = torch.zeros(b, self.hidden_channels, h, w, device=input_tensor.device)
         else:
             h_cur, c_cur = cur_state
-        if not self.init_done:
-            self.initialize_peephole(h, w, input_tensor.device)
-            self.init_done = True
-        pe = [getattr(self, n, None) for n in ("Wci", "Wcf", "Wco")]
-        if pe[0] is not None:
-            if self._pe_nonzero is None:  # one host sync per (re)load, not per step; they are never trained
-                self._pe_nonzero = any(bool(t.any()) for t in pe)
-            if not self._pe_nonzero:
-                pe = [None, None, None]  # identically zero in every reference run: skip the reads
+        pe = self._peephole_tensors(h, w, input_tensor.device)
         return K.ConvLSTMCellFn.apply(input_tensor.contiguous(), h_cur.contiguous(), c_cur.contiguous(), conv.weight,
                                       conv.bias, pe[0], pe[1], pe[2])
 
@@ -510,3 +514,22 @@ class ConvLSTM(nn.Module):
             ht, ct = self.LSTMlayer(input_tensor=x[:, t], cur_state=[ht, ct])
             output.append(ht)
         return torch.stack(output, 1), ht, ct
+
+    def forward_steps(self, x_all, ht, ct):
+        """x_all [S,B,C,H,W] (step-major) with given initial states -> ([h_1..h_S], h_S, c_S): what S calls
+        forward(x_t.unsqueeze(1), h, c) return (RFN_new.py:131-139 drives the layer one frame at a time).  On small maps
+        the whole sequence is one autograd node with the input projection / input and weight gradients time-batched
+        (rfn_hip.ops.ConvLSTMSeqFn)."""
+        layer, conv = self.LSTMlayer, self.LSTMlayer.conv[0]
+        S, B, C, H, W = x_all.shape
+        pe = layer._peephole_tensors(H, W, x_all.device)
+        if (x_all.is_cuda and ht is not None and ct is not None and pe[0] is None and layer.kernel_size[0] == 3
+                and K.convlstm_seq_supported(conv.weight, C, H, W)):
+            h_all, c_last = K.ConvLSTMSeqFn.apply(x_all, ht, ct, conv.weight, conv.bias)
+            hs = list(h_all.unbind(0))
+            return hs, hs[-1], c_last
+        hs = []
+        for t in range(S):
+            ht, ct = layer(input_tensor=x_all[t], cur_state=[ht, ct])
+            hs.append(ht)
+        return hs, ht, ct

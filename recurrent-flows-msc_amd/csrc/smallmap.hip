@@ -81,6 +81,7 @@ struct SmallmapParams {
     float slope_in;
     const bf16x8* packed;
     const float* bias;    // optional, per output channel (n / HW)
+    const float* add;     // optional [B][N] addend (e.g. the time-batched input projection of a recurrent layer)
     int act_out;          // 1: leaky_relu(slope_out) on the output
     float slope_out;
     float* out;           // [B][N]
@@ -151,6 +152,7 @@ __global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const Sma
         const int n = tile * 32 + nn, row = m0 + mm;
         if (row < p.B && n < p.N) {
             if (p.bias) s += p.bias[n / p.HW];
+            if (p.add) s += p.add[(long)row * p.N + n];
             if (p.act_out) s = s > 0.f ? s : s * p.slope_out;
             p.out[(long)row * p.N + n] = s;
         }
@@ -158,15 +160,15 @@ __global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const Sma
 }
 
 extern "C" int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float slope_in, const float* packed,
-                                         const float* bias, int act_out, float slope_out, float* out, float* a_out, int B,
-                                         int K, int N, int HW, rfn_stream_t stream) {
+                                         const float* bias, const float* add, int act_out, float slope_out, float* out,
+                                         float* a_out, int B, int K, int N, int HW, rfn_stream_t stream) {
     RFN_CHECK_ARG(a && packed && out && B >= 0 && K > 0 && N > 0 && HW > 0 && HW <= 16, -1);
     RFN_CHECK_ARG(K % 8 == 0 && K % HW == 0 && N % HW == 0, -2);
     RFN_CHECK_ARG((((uintptr_t)a | (uintptr_t)packed | (uintptr_t)(y ? y : a) | (uintptr_t)(a_out ? a_out : a)) & 15) == 0, -3);
     if (B == 0) return 0;
     SmallmapParams p;
     memset(&p, 0, sizeof(p));
-    p.a = a; p.y = y; p.slope_in = slope_in; p.packed = reinterpret_cast<const bf16x8*>(packed); p.bias = bias;
+    p.a = a; p.y = y; p.slope_in = slope_in; p.packed = reinterpret_cast<const bf16x8*>(packed); p.bias = bias; p.add = add;
     p.act_out = act_out; p.slope_out = slope_out; p.out = out; p.a_out = a_out;
     p.B = B; p.K = K; p.N = N; p.HW = HW; p.KS = (K + 15) / 16;
     dim3 grid((N + 31) / 32, (B + 31) / 32);

@@ -591,7 +591,7 @@ def smallmap_pack(w, H, W, transpose):
     return buf
 
 
-def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slope_in=0.0, want_a_out=False):
+def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slope_in=0.0, want_a_out=False, add=None):
     """out[B, n_channels, H, W] = a'[B, C, H, W] (as rows) x packed (+ bias, leaky_relu) -- rfn_smallmap_dense_bf16x3.
     With y: a' = a * (y > 0 ? 1 : slope_in); returns (out, a') when want_a_out."""
     a = a.contiguous()
@@ -600,8 +600,9 @@ def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slo
     out = torch.empty((B, n_channels, H, W), device=a.device, dtype=torch.float32)
     a_out = torch.empty_like(a) if want_a_out else None
     yc = None if y is None else y.contiguous()
+    addc = None if add is None else add.contiguous()  # held until the launch is enqueued
     L.call("rfn_smallmap_dense_bf16x3", L.dev(a), L.dev(yc), ctypes.c_float(slope_in), L.dev(packed), L.dev(bias),
-           _i(0 if slope_out is None else 1), ctypes.c_float(0.0 if slope_out is None else slope_out), L.dev(out),
+           L.dev(addc), _i(0 if slope_out is None else 1), ctypes.c_float(0.0 if slope_out is None else slope_out), L.dev(out),
            L.dev(a_out), _i(B), _i(K), _i(n_channels * HW), _i(HW))
     return (out, a_out) if want_a_out else out
 
@@ -687,3 +688,75 @@ class ConvLSTMCellFn(torch.autograd.Function):
         ghp_ = torch.empty_like(h)
         conv2d_raw(gcc, None, pack_weight(w, True), Cx + Hc, ks, 0, None, None, 0, out1=gx, out2=ghp_, cout_split=Cx)
         return gx, ghp_, gc_prev, gw, gb, None, None, None
+
+
+def convlstm_seq_supported(w, Cx, H, W):
+    """time-batched ConvLSTM path: 3x3 kernel on a small map, both weight halves dense-packable"""
+    Hc = int(w.shape[0]) // 4
+    return (CONV_PRECISION == "bf16x3" and tuple(w.shape[2:]) == (3, 3) and H * W <= 16 and (Cx * H * W) % 8 == 0
+            and (Hc * H * W) % 8 == 0 and int(w.shape[1]) == Cx + Hc)
+
+
+class ConvLSTMSeqFn(torch.autograd.Function):
+    """A whole ConvLSTM sequence (Utils/modules.py:396-414 looping :355-377) on a small map as ONE autograd node.
+    conv(cat(x_t, h_{t-1})) = Wx*x_t + Wh*h_{t-1}: the input projection of all S steps is one time-batched dense
+    product, only Wh*h_{t-1} (Hc of the Cx+Hc input channels) stays in the recurrence; the backward pass keeps only
+    Wh^T*gcc_t in its loop and computes the input gradient, the weight gradient and the bias gradient once over the S
+    steps.  x_all [S,B,Cx,H,W] -> h_all [S,B,Hc,H,W], c_S."""
+
+    @staticmethod
+    def forward(ctx, x_all, h0, c0, w, b):
+        S, B, Cx, H, W = (int(v) for v in x_all.shape)
+        Hc, HW = int(w.shape[0]) // 4, H * W
+        x_all, h0, c0 = x_all.contiguous(), h0.contiguous(), c0.contiguous()
+        wd = w.detach()
+        wx, wh = wd[:, :Cx].contiguous(), wd[:, Cx:].contiguous()
+        pk_xf, pk_hf = smallmap_pack(wx, H, W, False), smallmap_pack(wh, H, W, False)
+        pre = smallmap_dense(x_all.view(S * B, Cx, H, W), pk_xf, 4 * Hc, bias=None if b is None else b.detach())
+        pre = pre.view(S, B, 4 * Hc, H, W)
+        h_all = torch.empty((S, B, Hc, H, W), device=x_all.device, dtype=torch.float32)
+        c_all = torch.empty((S, B, Hc, H, W), device=x_all.device, dtype=torch.float32)
+        gates = torch.empty((S, B, 4 * Hc, H, W), device=x_all.device, dtype=torch.float32)
+        h_prev, c_prev = h0, c0
+        ns = Hc * HW
+        for t in range(S):
+            cc = smallmap_dense(h_prev, pk_hf, 4 * Hc, add=pre[t])
+            L.call("rfn_convlstm_gates_fwd_f32", L.dev(cc), L.dev(c_prev), _l(ns), None, None, None, L.dev(h_all[t]),
+                   _l(ns), L.dev(c_all[t]), _l(ns), L.dev(gates[t]), _i(B), _i(Hc), _i(HW))
+            h_prev, c_prev = h_all[t], c_all[t]
+        ctx.save_for_backward(x_all, h0, c0, w, h_all, c_all, gates)
+        ctx.has_bias = b is not None
+        return h_all, c_all[S - 1]
+
+    @staticmethod
+    def backward(ctx, g_hall, g_cS):
+        x_all, h0, c0, w, h_all, c_all, gates = ctx.saved_tensors
+        S, B, Cx, H, W = (int(v) for v in x_all.shape)
+        Hc, HW = int(w.shape[0]) // 4, H * W
+        ns = Hc * HW
+        wd = w.detach()
+        wx, wh = wd[:, :Cx].contiguous(), wd[:, Cx:].contiguous()
+        pk_xb, pk_hb = smallmap_pack(wx, H, W, True), smallmap_pack(wh, H, W, True)
+        g_hall = None if g_hall is None else g_hall.contiguous()
+        gcc = torch.empty_like(gates)
+        gh_rec, gc = None, (None if g_cS is None else g_cS.contiguous())
+        for t in range(S - 1, -1, -1):
+            if g_hall is None:
+                gh = gh_rec
+            elif gh_rec is None:
+                gh = g_hall[t]
+            else:
+                gh = g_hall[t] + gh_rec
+            c_prev = c_all[t - 1] if t > 0 else c0
+            gc_prev = torch.empty_like(c0)
+            L.call("rfn_convlstm_gates_bwd_f32", L.dev(gates[t]), L.dev(c_prev), _l(ns), L.dev(c_all[t]), _l(ns),
+                   L.dev(gh), _l(ns if gh is not None else 0), L.dev(gc), _l(ns if gc is not None else 0), None, None, None,
+                   L.dev(gcc[t]), L.dev(gc_prev), _l(ns), _i(B), _i(Hc), _i(HW))
+            gh_rec = smallmap_dense(gcc[t], pk_hb, Hc)
+            gc = gc_prev
+        G = gcc.view(S * B, 4 * Hc, H, W)
+        gx_all = smallmap_dense(G, pk_xb, Cx).view(S, B, Cx, H, W) if ctx.needs_input_grad[0] else None
+        h_prev_all = torch.cat([h0.unsqueeze(0), h_all[:S - 1]], 0).view(S * B, Hc, H, W)
+        gw = conv2d_wgrad(x_all.view(S * B, Cx, H, W), h_prev_all, G, 4 * Hc, 3)
+        gb = G.sum(dim=(0, 2, 3)) if ctx.has_bias else None
+        return gx_all, gh_rec, gc, gw, gb

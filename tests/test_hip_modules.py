@@ -279,6 +279,39 @@ def test_rfn_loss_end_to_end(golden, name):
                     and "LSTMlayer.Wc" not in k}, 5e-3, 5e-4)
 
 
+@pytest.mark.parametrize("B,Cx,Hc,H,W,S", [(4, 24, 10, 2, 2, 5), (33, 6, 4, 4, 4, 3), (3, 5, 6, 2, 2, 4)])
+def test_convlstm_sequence_node_equals_per_step_cells(B, Cx, Hc, H, W, S, conv_precision):
+    """ConvLSTM.forward_steps (one autograd node, time-batched input projection and gradients) against S calls of the
+    cell (Utils/modules.py:355-377 driven per frame by RFN_new.py:131-139): states and every gradient.  The third
+    case has channel counts the dense kernels do not take and must fall back to the per-step cells."""
+    from Utils import ConvLSTM
+    torch.manual_seed(11)
+    m = ConvLSTM(Cx, Hc, (3, 3), bias=True).cuda()
+    g = torch.Generator().manual_seed(12)
+    x = torch.randn(S, B, Cx, H, W, generator=g).cuda()
+    h0, c0 = torch.randn(B, Hc, H, W, generator=g).cuda(), torch.randn(B, Hc, H, W, generator=g).cuda()
+    gw = [torch.randn(B, Hc, H, W, generator=g).cuda() for _ in range(S)]
+    gcl = torch.randn(B, Hc, H, W, generator=g).cuda()
+
+    def run(seq):
+        xs, hh, cc = x.clone().requires_grad_(True), h0.clone().requires_grad_(True), c0.clone().requires_grad_(True)
+        m.zero_grad(set_to_none=True)
+        if seq:
+            hs, hl, cl = m.forward_steps(xs, hh, cc)
+        else:
+            hs, hl, cl = [], hh, cc
+            for t in range(S):
+                _, hl, cl = m(xs[t].unsqueeze(1), hl, cl)
+                hs.append(hl)
+        (sum((a * b).sum() for a, b in zip(hs, gw)) + (cl * gcl).sum()).backward()
+        conv = m.LSTMlayer.conv[0]
+        return [torch.stack(hs), cl, xs.grad, hh.grad, cc.grad, conv.weight.grad.clone(), conv.bias.grad.clone()]
+    a, b = run(True), run(False)
+    for name, u, v in zip(["h", "c_last", "gx", "gh0", "gc0", "gw", "gb"], a, b):
+        err = float((u - v).abs().max() / (v.abs().max() + 1e-12))
+        assert err < 5e-5, (name, err)
+
+
 def test_graph_captured_step_equals_eager_step():
     """Solver in hipGraph mode (fwd+bwd captured, replayed) produces the same loss and gradients as the eager step."""
     import __graft_entry__ as ge
