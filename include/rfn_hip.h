@@ -88,8 +88,8 @@ int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, i
  *   out = g * act'(y) * exp(logs[c])       (= grad wrt u, what the producer's weight- and data-gradient consume)
  *   part[row][c][0] = Σ out,  part[row][c][1] = Σ g*y   over the pixels of partial-sum row `row`
  * so grad b = Σ_rows part[.,c,0] and grad logs = Σ_rows part[.,c,1] need only a tiny reduction afterwards.
- * rows = rfn_conv2d_dgrad_act_rows_bf16x3(N,H,W,ks,Cout); part holds rows*Cout*2 floats; Cout % 64 == 0. */
-int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout);
+ * rows = rfn_conv2d_dgrad_act_rows_bf16x3(N,H,W,ks,Cout,Cin); part holds rows*Cout*2 floats; Cout % 64 == 0. */
+int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout, int Cin);
 int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Cin, const float* wpk, const float* y, long y_ns,
                                 const float* logs, int act, float* out, long out_ns, float* part, int Cout, int N,
                                 int H, int W, int ks, rfn_stream_t stream);

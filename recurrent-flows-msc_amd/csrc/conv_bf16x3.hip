@@ -392,7 +392,9 @@ static int launch_conv_b3(ConvParams& p, hipStream_t s) {
 static int dispatch_conv_b3(ConvParams& p, int ks, hipStream_t s);
 
 // number of partial-sum rows rfn_conv2d_dgrad_act_bf16x3 writes for (N,H,W,ks,Cout): pixel tiles x waves along pixels
-extern "C" int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout) {
+static bool conv1x1_ws_eligible(int ks, int Cin, int C2, int Cout, long npix);
+extern "C" int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout, int Cin) {
+    if (conv1x1_ws_eligible(ks, Cin, 0, Cout, (long)N * H * W)) return (int)(((long)N * H * W + 31) / 32);
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.N = N; p.H = H; p.W = W; p.Cout = Cout;
@@ -456,10 +458,164 @@ extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, cons
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight-stationary 1x1
+// The flow's hidden 1x1 convolution (Hd -> Hd = 256 -> 256, forward and data gradient, 60 launches per step on up to
+// 622 592 pixels) with the weights held in REGISTERS: 8 waves, wave w owns output channels [32w, 32w+32) and keeps their
+// 32 x 256 (hi, lo) slab in 128 VGPRs for the whole launch, so the only LDS traffic is the activation tile (staged once,
+// read by all 8 waves) and nothing but activations is streamed.  One persistent workgroup per CU sweeps 64-pixel
+// tiles; the loads of tile t+1 are in flight while tile t is multiplied and stored (double-buffered LDS, one barrier
+// per tile).  Per tile and CU: 96 MFMAs per wave against 64 KB read + 64 KB written -> the kernel sits on the HBM roof
+// instead of the issue / LDS / barrier overheads of the generic tile kernel above (which re-stages the 256 x 32
+// weight chunk for every 64 pixels).
+template <int NSTEPS>
+__global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p, const int n_tiles, const int hw_shift) {
+    constexpr int NG = NSTEPS * 2;  // 8-channel units per pixel
+    constexpr int TP = 32;          // pixels per tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bf16x8* Bs = reinterpret_cast<bf16x8*>(lds_raw);                       // [2 buffers][plane][NG][TP]
+    float* ep = reinterpret_cast<float*>(Bs + 2 * 2 * NG * TP);            // [2][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int HW = p.H * p.W;
+    const long total = (long)p.N * HW;
+    const int co_base = blockIdx.y * 256 + wave * 32;
+
+    // weights -> registers (packed unit index ((s*2 + plane)*2 + kk)*CoutP + co, see pack_weight_b3_kernel)
+    bf16x8 wh[NSTEPS], wl[NSTEPS];
+    {
+        const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpk) + co_base + l31;
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+            const bool ok = s < p.Cin8;  // Cin8 holds the number of 16-channel steps
+            const int sc = ok ? s : 0;
+            const bf16x8 h = wp[(long)((sc * 2 + 0) * 2 + kk) * p.CoutP];
+            const bf16x8 l = wp[(long)((sc * 2 + 1) * 2 + kk) * p.CoutP];
+            const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+            wh[s] = ok ? h : z;
+            wl[s] = ok ? l : z;
+        }
+    }
+    if (p.ep_mode != 0) {
+        for (int c = tid; c < 256; c += 512) {
+            const int co = blockIdx.y * 256 + c;
+            float e0 = 0.f, e1 = 1.f;
+            if (co < p.Cout) {
+                if (p.ep_mode != 4) e0 = p.p0[co];
+                if (p.ep_mode == 1 || p.ep_mode == 4) e1 = expf(p.p1[co]);
+                if (p.ep_mode == 2) e1 = expf(3.f * p.p1[co]);
+            }
+            ep[c] = e0;
+            ep[256 + c] = e1;
+        }
+    }
+
+    // Staging role: pixel l31 of the tile, channel units 2*wave + kk + 16*i (i < NG/16).  Loads go through one buffer
+    // descriptor: a per-lane 32-bit byte offset (frame, pixel, kk) plus a scalar channel offset, so the loads of a tile
+    // need no per-load 64-bit address registers (they would not fit next to the weights).
+    constexpr int NU = NG / 16;  // units per thread and tile
+    const int Cin = p.C1;
+    const unsigned long in_bytes = (unsigned long)p.N * (unsigned long)p.in1_ns * 4ul;
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(p.in1), 0,
+                                                        in_bytes > 0xFFFFFFFFul ? 0xFFFFFFFFu : (unsigned)in_bytes, 0x00020000);
+    float stg[NU][8];
+    bool sval = false;
+    auto split_q = [&](long q, int& n, int& pix) {
+        if (hw_shift >= 0) {
+            n = (int)(q >> hw_shift);
+            pix = (int)(q & (HW - 1));
+        } else {
+            n = (int)(q / HW);
+            pix = (int)(q - (long)n * HW);
+        }
+    };
+    auto prefetch = [&](int tile) {
+        const long q = (long)tile * TP + l31;
+        sval = tile < n_tiles && q < total;
+        int n, pix;
+        split_q(sval ? q : 0, n, pix);
+        const unsigned voff = (unsigned)(((long)n * p.in1_ns + pix + (long)kk * 8 * HW) * 4);
+#pragma unroll
+        for (int i = 0; i < NU; ++i)
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const int ch0 = (2 * wave + 16 * i) * 8 + c;  // scalar; + 8*kk per lane (in voff)
+                const int soff = (ch0 < Cin ? ch0 : 0) * HW * 4;  // kk = 1 lanes past Cin: in-bounds or zero (descriptor), masked in commit
+                stg[i][c] = __uint_as_float(__builtin_amdgcn_raw_buffer_load_b32(rsrc, voff, soff, 0));
+            }
+    };
+    auto commit = [&](int buf) {
+        bf16x8* dst = Bs + (long)buf * 2 * NG * TP + l31;
+#pragma unroll
+        for (int i = 0; i < NU; ++i) {
+            const int g = 2 * wave + kk + 16 * i;
+            bf16x8 hi, lo;
+#pragma unroll
+            for (int c = 0; c < 8; ++c) {
+                const float v = (sval && g * 8 + c < Cin) ? stg[i][c] : 0.f;
+                const __bf16 h = (__bf16)v;
+                hi[c] = h;
+                lo[c] = (__bf16)(v - (float)h);
+            }
+            dst[(0 * NG + g) * TP] = hi;
+            dst[(1 * NG + g) * TP] = lo;
+        }
+    };
+
+    int tile = blockIdx.x, buf = 0;
+    prefetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        commit(buf);
+        prefetch(tile + gridDim.x);         // unconditional (clamped): in flight during the MFMAs and stores below
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        const bf16x8* bb = Bs + (long)buf * 2 * NG * TP + kk * TP + l31;
+        f32x16 acc[1][1];
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[0][0][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+            const bf16x8 bh = bb[(0 * NG + 2 * s) * TP];
+            const bf16x8 bl = bb[(1 * NG + 2 * s) * TP];
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s], bh, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s], bl, acc[0][0], 0, 0, 0);
+            acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s], bh, acc[0][0], 0, 0, 0);
+        }
+        int pn[1], ppix[1];
+        bool pvalid[1];
+        const long q = (long)tile * TP + l31;
+        pvalid[0] = q < total;
+        split_q(pvalid[0] ? q : 0, pn[0], ppix[0]);
+        conv_epilogue<1, 1, 256>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile);
+    }
+}
+
+static bool conv1x1_ws_eligible(int ks, int Cin, int C2, int Cout, long npix) {
+    static const bool off = getenv("RFN_CONV_WS") && atoi(getenv("RFN_CONV_WS")) == 0;
+    return !off && ks == 1 && C2 == 0 && Cout % 256 == 0 && Cin > 128 && Cin <= 256 && npix >= 64L * 256;
+}
+
+static int launch_conv1x1_ws(ConvParams& p, hipStream_t s) {
+    const int HW = p.H * p.W;
+    const long total = (long)p.N * HW;
+    const int n_tiles = (int)((total + 31) / 32);
+    int hw_shift = -1;
+    if ((HW & (HW - 1)) == 0) hw_shift = ilog2(HW);
+    p.ksplit = 1;
+    const size_t lds = (size_t)2 * 2 * 32 * 32 * 16 + 2 * 256 * 4;
+    auto kern = conv1x1_ws_kernel<16>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(n_tiles < 256 ? n_tiles : 256, p.Cout / 256);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p, n_tiles, hw_shift);
+    return 0;
+}
+
 static int dispatch_conv_b3(ConvParams& p, int ks, hipStream_t s) {
     const int Cout = p.Cout, N = p.N, H = p.H, W = p.W;
     const bool few_px = (long)N * H * W * ((Cout + 127) / 128) < 256L * 128;
     int rc;
+    if (conv1x1_ws_eligible(ks, p.C1 + p.C2, p.C2, Cout, (long)N * H * W)) return launch_conv1x1_ws(p, s);
     if (ks == 3) {
         if (Cout <= 32)
             rc = launch_conv_b3<3, 1, 4, 1, 1, 16>(p, s);   // 32 co x 128 px

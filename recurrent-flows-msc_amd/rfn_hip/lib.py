@@ -33,7 +33,7 @@ SIGNATURES = {
                               _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
     "rfn_packed_weight_size_bf16x3": [_c_i, _c_i, _c_i],
     "rfn_pack_conv_weight_bf16x3": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
-    "rfn_conv2d_dgrad_act_rows_bf16x3": [_c_i, _c_i, _c_i, _c_i, _c_i],
+    "rfn_conv2d_dgrad_act_rows_bf16x3": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_conv2d_dgrad_act_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_i, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,
                                     _c_i, _c_i, _c_s],
     "rfn_pack_conv_weights_batched_bf16x3": [_c_f, _c_i, _c_s],

@@ -132,11 +132,11 @@ def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks):
     yp, yns = L.frames(y, "y")
     gu = torch.empty((N, Cout, H, W), device=gin.device, dtype=torch.float32)
     up, uns = L.frames(gu, "gu")
-    rows = L.load().rfn_conv2d_dgrad_act_rows_bf16x3(N, H, W, ks, Cout)
+    rows = L.load().rfn_conv2d_dgrad_act_rows_bf16x3(N, H, W, ks, Cout, Cin)
     part = torch.empty((rows, Cout, 2), device=gin.device, dtype=torch.float32)
     L.call("rfn_conv2d_dgrad_act_bf16x3", gp, _l(gns), _i(Cin), L.dev(wpk_flip), yp, _l(yns), L.dev(logs), _i(act), up,
            _l(uns), L.dev(part), _i(Cout), _i(N), _i(H), _i(W), _i(ks),
-           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W) + "+actbwd", 2.0 * N * H * W * Cin * Cout * ks * ks,
+           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W, Cin) + "+actbwd", 2.0 * N * H * W * Cin * Cout * ks * ks,
                  "N%d %d->%d %dx%d k%d dgrad+actbwd" % (N, Cin, Cout, H, W, ks),
                  4.0 * (N * H * W * (Cin + 2 * Cout) + Cin * Cout * ks * ks)))
     sums = part.sum(0)
@@ -190,7 +190,7 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
            L.dev(wpk), o1p, _l(o1ns), o2p,
            _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W), _i(ks),
            _i(ep_mode), L.dev(p0), L.dev(p1), _i(act),
-           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W) if b3 else conv_kernel_name(Cout, ks, N * H * W),
+           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W, (C1 + C2) if C2 == 0 else None) if b3 else conv_kernel_name(Cout, ks, N * H * W),
                  2.0 * N * H * W * (C1 + C2) * Cout * ks * ks,
                  "N%d %d+%d->%d %dx%d k%d ep%d%s" % (N, C1, C2, Cout, H, W, ks, ep_mode,
                                                   "" if cout_split == Cout else " split"),
@@ -198,12 +198,14 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
     return out1
 
 
-def conv_b3_kernel_name(Cout, ks, npix=1 << 30):
+def conv_b3_kernel_name(Cout, ks, npix=1 << 30, Cin=None):
     """the template instantiation rfn_conv2d_fwd_bf16x3 dispatches to (mirrors csrc/conv_bf16x3.hip)"""
     few = npix * ((Cout + 127) // 128) < 256 * 128
     if ks == 3:
         cfg = "1,4,1,1" if Cout <= 32 else ("2,2,1,1" if few else "2,2,1,2")
         return "conv_b3_kernel<3,%s,16>" % cfg
+    if ks == 1 and Cin is not None and Cout % 256 == 0 and 128 < Cin <= 256 and npix >= 64 * 256 and os.environ.get("RFN_CONV_WS") != "0":
+        return "conv1x1_ws_kernel<16>"
     cfg = "1,4,1,1" if Cout <= 32 else ("2,2,1,1" if (few or Cout <= 64) else ("2,2,2,2" if Cout <= 128 else "4,1,2,2"))
     return "conv_b3_kernel<1,%s,32>" % cfg
 

@@ -110,6 +110,8 @@ CONV_CASES = [
     (2, 40, 0, 33, 3, 5, 1),     # 3x5 map
     (32, 512, 200, 800, 2, 2, 3),  # ConvLSTM conv: few pixels, huge K -> 32-pixel tiles + split-K (atomic combine)
     (6, 100, 0, 200, 4, 4, 1),   # few-pixel 1x1, split-K
+    (70, 256, 0, 256, 16, 16, 1),   # weight-stationary 1x1 kernel (>= 16384 pixels, Cout 256, 128 < Cin <= 256)
+    (131, 200, 0, 256, 12, 12, 1),  # same kernel: Cin not a multiple of 16, non power-of-two map, ragged last tile
 ]
 
 
