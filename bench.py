@@ -82,7 +82,14 @@ def kernel_roofline(rec, steps):
             h["ms"] += ms
             h["flops"] += meta[2]
             h["bytes"] += meta[4]
-    mfma = {k: v for k, v in groups.items() if v["flops"] > 0}  # (shell kernels carry bytes only)
+    # the roofline line is per kernel SYMBOL, as rocprofv3 --stats groups launches (epilogue variants such as
+    # "+actbwd" are run-time modes of one symbol; the table below keeps them apart)
+    syms = {}
+    for k, v in groups.items():
+        g = syms.setdefault(k.split("+")[0], {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        for f in g:
+            g[f] += v[f]
+    mfma = {k: v for k, v in syms.items() if v["flops"] > 0}  # (shell kernels carry bytes only)
     dom = max(mfma, key=lambda k: mfma[k]["ms"])
     d = mfma[dom]
     tot_ms = sum(v["ms"] for v in groups.values())
