@@ -112,6 +112,12 @@ int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_st
 int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw, int F, int HW,
                           rfn_stream_t stream);
 /* out[n][tap*Cin+ci][y][x] = in[n][ci][y+dy-1][x+dx-1] (0 outside); two-source input; out dense [N,9*Cin,H,W]. */
+/* 3x3 (pad 1) weight gradient without the im2col buffer (W % 8 == 0): gw[Cout][9*(C1+C2)] += sum over frames and
+ * pixels of g[co][px] * in[ci][px + tap], column index tap*Cin + ci as for the GEMM on rfn_im2col3x3_f32's output.
+ * gw must be zeroed by the caller (split over pixel stages, atomic combine). */
+int rfn_conv3x3_wgrad_implicit_bf16x3(const float* g, long g_ns, int Cout, const float* in1, long in1_ns, int C1,
+                                      const float* in2, long in2_ns, int C2, float* gw, int F, int H, int W,
+                                      rfn_stream_t stream);
 int rfn_im2col3x3_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2, float* out, int N,
                       int H, int W, rfn_stream_t stream);
 

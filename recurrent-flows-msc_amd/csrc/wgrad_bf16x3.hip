@@ -22,12 +22,17 @@ struct GemmWgradParams {
     int F, HW;  // frames, pixels per frame (HW % 4 == 0)
     long total; // F*HW
     int n_stages;
+    // implicit 3x3 mode (IMPL = 1): operand B row n = tap*Cin + ci is the input plane ci shifted by the tap, read straight
+    // from the convolution's (two-source) input -- b = in1, b2 = in2 -- instead of from an im2col buffer in HBM
+    const float* b2;
+    long b2_ns;
+    int C1, C2, H, W;
 };
 
 // WM x WN waves (4 or 8) of TM x TN 32x32 tiles each.  The 8-wave 256-row configurations read both operands of the
 // big level-0 / level-1 gradients exactly once (a 128 x 128 tiling of a 256 x 256 gradient reads each of them twice,
 // and those launches sit on the HBM roof).
-template <int WM, int WN, int TM, int TN, int KP>
+template <int WM, int WN, int TM, int TN, int KP, int IMPL = 0>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmWgradParams p) {
     constexpr int NT = 64 * WM * WN;
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
@@ -67,6 +72,27 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
     // commit: unconditional (clamped rows / pixels, no select on a loaded value, no control flow) -- otherwise the
     // compiler waits for HBM right behind the loads and nothing overlaps.  Masks are applied in commit().
     bool okq[2] = {false, false};
+    // implicit mode: per unit (fixed row n = tap*Cin + ci) the plane pointer, frame stride and tap offsets; per stage the
+    // 8 pixels of a unit lie in one image row (W % 8 == 0), shifted by dx they need one element beyond either end
+    const float* uplane[IMPL ? BU : 1];
+    long uns[IMPL ? BU : 1];
+    int udy[IMPL ? BU : 1], udx[IMPL ? BU : 1];
+    float bedge[IMPL ? BU : 1];
+    unsigned rowmask = 0, edgemask = 0;
+    if (IMPL) {
+        const int Cin = p.C1 + p.C2;
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            int row = n0 + r0 + u * (NT / NU);
+            if (row >= p.N) row = 0;
+            const int tap = row / Cin, ci = row - tap * Cin;
+            udy[u] = tap / 3 - 1;
+            udx[u] = tap % 3 - 1;
+            const bool first = ci < p.C1;
+            uplane[u] = first ? p.b + (long)ci * p.HW : p.b2 + (long)(ci - p.C1) * p.HW;
+            uns[u] = first ? p.b_ns : p.b2_ns;
+        }
+    }
     auto prefetch = [&](int stage) {
         const unsigned q0 = (unsigned)stage * KP + 8u * kg;
         long offa[2], offb[2];
@@ -86,13 +112,49 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 #pragma unroll
             for (int h = 0; h < 2; ++h) ast[u][h] = *reinterpret_cast<const float4*>(base + offa[h]);
         }
+        if (IMPL) {
+            const unsigned qq = okq[0] ? q0 : 0u;
+            const unsigned f = qq / uHW, pix = qq - f * uHW;
+            const int y = (int)(pix / (unsigned)p.W), x0 = (int)(pix - (unsigned)y * (unsigned)p.W);
+            rowmask = 0;
+            edgemask = 0;
 #pragma unroll
-        for (int u = 0; u < BU; ++u) {
-            const int row = n0 + r0 + u * (NT / NU);
-            const float* base = p.b + (long)(row < p.N ? row : 0) * p.HW;
+            for (int u = 0; u < BU; ++u) {
+                const int yy = y + udy[u];
+                const bool rok = yy >= 0 && yy < p.H;
+                const float* src = uplane[u] + (long)f * uns[u] + (rok ? yy : y) * p.W + x0;
+                bst[u][0] = *reinterpret_cast<const float4*>(src);
+                bst[u][1] = *reinterpret_cast<const float4*>(src + 4);
+                const bool eok = udx[u] < 0 ? x0 > 0 : x0 + 8 < p.W;  // the element beyond the end, inside the row?
+                bedge[u] = src[eok ? (udx[u] < 0 ? -1 : 8) : 0];
+                rowmask |= (rok ? 1u : 0u) << u;
+                edgemask |= (eok ? 1u : 0u) << u;
+            }
+        } else {
 #pragma unroll
-            for (int h = 0; h < 2; ++h) bst[u][h] = *reinterpret_cast<const float4*>(base + offb[h]);
+            for (int u = 0; u < BU; ++u) {
+                const int row = n0 + r0 + u * (NT / NU);
+                const float* base = p.b + (long)(row < p.N ? row : 0) * p.HW;
+#pragma unroll
+                for (int h = 0; h < 2; ++h) bst[u][h] = *reinterpret_cast<const float4*>(base + offb[h]);
+            }
         }
+    };
+    auto split_store_shift = [&](const float4 (&src)[2], float edge, int dx, bool okr, bool eok, bf16x8* hi_p, bf16x8* lo_p) {
+        const float v[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float left = c == 0 ? (eok ? edge : 0.f) : v[c > 0 ? c - 1 : 0];
+            const float right = c == 7 ? (eok ? edge : 0.f) : v[c < 7 ? c + 1 : 7];
+            float x = dx < 0 ? left : (dx > 0 ? right : v[c]);
+            x = (okr && okq[0]) ? x : 0.f;
+            const __bf16 h = (__bf16)x;
+            hi[c] = h;
+            lo[c] = (__bf16)(x - (float)h);
+        }
+        *hi_p = hi;
+        *lo_p = lo;
     };
     auto split_store = [&](const float4 (&src)[2], bool okr, bf16x8* hi_p, bf16x8* lo_p) {
         const float v[8] = {src[0].x, src[0].y, src[0].z, src[0].w, src[1].x, src[1].y, src[1].z, src[1].w};
@@ -116,7 +178,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
             const int o = (r0 + u * (NT / NU)) * RS + kg;
-            if (BX || r0 + u * (NT / NU) < BN) split_store(bst[u], n0 + r0 + u * (NT / NU) < p.N, Bh + o, Bl + o);
+            if (BX || r0 + u * (NT / NU) < BN) {
+                const bool okr = n0 + r0 + u * (NT / NU) < p.N;
+                if (IMPL)
+                    split_store_shift(bst[u], bedge[u], udx[u], okr && ((rowmask >> u) & 1u), (edgemask >> u) & 1u, Bh + o,
+                                      Bl + o);
+                else
+                    split_store(bst[u], okr, Bh + o, Bl + o);
+            }
         }
     };
 
@@ -168,7 +237,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
         }
 }
 
-template <int WM, int WN, int TM, int TN, int KP>
+template <int WM, int WN, int TM, int TN, int KP, int IMPL = 0>
 static void launch_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
     p.n_stages = (int)((p.total + KP - 1) / KP);
@@ -177,7 +246,7 @@ static void launch_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
     int S = (WM * WN == 8 ? 256 : 1024) / tiles;  // 8-wave tiles: one workgroup per CU
     if (S < 1) S = 1;
     if (S > p.n_stages) S = p.n_stages;
-    auto kern = gemm_wgrad_b3_kernel<WM, WN, TM, TN, KP>;
+    auto kern = gemm_wgrad_b3_kernel<WM, WN, TM, TN, KP, IMPL>;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
@@ -212,6 +281,31 @@ extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const flo
         launch_gemm_wgrad<4, 1, 2, 2, 32>(p, s);   // 256 x 64
     else
         launch_gemm_wgrad<2, 2, 2, 2, 64>(p, s);   // 128 x 128
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// 3x3 weight gradient without the im2col buffer: gw[co][tap*Cin + ci] = sum_{frames,pixels} g[co][px] * in[ci][px + tap]
+// (pad 1), the shifted planes built while staging (rows of one image row, W % 8 == 0).  Same output layout as the GEMM on
+// rfn_im2col3x3_f32's buffer.
+extern "C" int rfn_conv3x3_wgrad_implicit_bf16x3(const float* g, long g_ns, int Cout, const float* in1, long in1_ns, int C1,
+                                                 const float* in2, long in2_ns, int C2, float* gw, int F, int H, int W,
+                                                 rfn_stream_t stream) {
+    RFN_CHECK_ARG(g && in1 && gw && Cout > 0 && C1 > 0 && C2 >= 0 && (C2 == 0 || in2) && F >= 0 && H > 0 && W > 0, -1);
+    RFN_CHECK_ARG(W % 8 == 0 && g_ns % 4 == 0 && in1_ns % 4 == 0 && (C2 == 0 || in2_ns % 4 == 0), -2);
+    RFN_CHECK_ARG((((uintptr_t)g | (uintptr_t)in1 | (uintptr_t)(C2 ? in2 : in1)) & 15) == 0, -3);
+    RFN_CHECK_ARG((long)F * H * W < (1L << 31) - 4096, -4);
+    if (F == 0) return 0;
+    GemmWgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = g; p.a_ns = g_ns; p.M = Cout; p.b = in1; p.b_ns = in1_ns; p.b2 = C2 ? in2 : in1; p.b2_ns = C2 ? in2_ns : in1_ns;
+    p.C1 = C1; p.C2 = C2; p.H = H; p.W = W; p.N = 9 * (C1 + C2); p.gw = gw; p.F = F; p.HW = H * W;
+    p.total = (long)F * H * W;
+    hipStream_t s = (hipStream_t)stream;
+    if (Cout > 128 && p.total >= 100000)
+        launch_gemm_wgrad<4, 2, 2, 3, 64, 1>(p, s);   // 256 x 192, 8 waves
+    else
+        launch_gemm_wgrad<2, 2, 2, 2, 64, 1>(p, s);   // 128 x 128
     RFN_LAUNCH_CHECK();
     return 0;
 }

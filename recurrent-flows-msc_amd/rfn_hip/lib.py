@@ -38,6 +38,8 @@ SIGNATURES = {
                                     _c_i, _c_i, _c_s],
     "rfn_pack_conv_weights_batched_bf16x3": [_c_f, _c_i, _c_s],
     "rfn_gemm_wgrad_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_s],
+    "rfn_conv3x3_wgrad_implicit_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_i,
+                                          _c_s],
     "rfn_im2col3x3_f32": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_i, _c_s],
     "rfn_packed_weight_size": [_c_i, _c_i, _c_i],
     "rfn_pack_conv_weight_f32": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],

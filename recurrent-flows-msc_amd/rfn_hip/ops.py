@@ -256,6 +256,19 @@ def conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena=None):
     if ks == 1:
         x = in1 if in2 is None else torch.cat((in1, in2), 1)
         return gemm_wgrad(g, x, Cout, Cin, arena).view(Cout, Cin, 1, 1)
+    if Cin <= Cout and W % 8 == 0 and os.environ.get("RFN_WGRAD_IMPLICIT") != "0":
+        # shifted input planes are built while staging: no im2col buffer (rfn_conv3x3_wgrad_implicit_bf16x3)
+        i1p, i1ns = L.frames(in1, "in1")
+        i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
+        gp, gns = L.frames(g, "g")
+        gw = _zeros(arena, Cout, 9 * Cin, device=in1.device)
+        big = Cout > 128 and N * H * W >= 100000
+        L.call("rfn_conv3x3_wgrad_implicit_bf16x3", gp, _l(gns), _i(Cout), i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2),
+               L.dev(gw), _i(N), _i(H), _i(W),
+               meta=("wgrad", "gemm_wgrad_b3_kernel<%s,1>" % ("4,2,2,3,64" if big else "2,2,2,2,64"),
+                     2.0 * N * H * W * Cout * 9 * Cin, "F%d %dx%d HW%d implicit3x3" % (N, Cout, 9 * Cin, H * W),
+                     4.0 * (N * H * W * (Cout + Cin) + Cout * 9 * Cin)))
+        return gw.view(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
     if Cin <= Cout:
         i1p, i1ns = L.frames(in1, "in1")
         i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
