@@ -243,9 +243,13 @@ static void launch_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
     p.n_stages = (int)((p.total + KP - 1) / KP);
     size_t lds = (size_t)2 * (BM + BN) * (KP / 8 + 1) * 16;
     int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    int S = (WM * WN == 8 ? 256 : 1024) / tiles;  // 8-wave tiles: one workgroup per CU
+    // K split: every workgroup ends with BM x BN float atomics into the SAME gw tile, and the chip retires only ~1.3 TB/s
+    // of atomic bytes -- 1024 workgroups x 64 KB is 50 us of atomics on a problem whose GEMM takes 10.  So: as many
+    // workgroups as the CUs can hold at once (8-wave tiles: one per CU, 4-wave: two), and at least 4 stages each.
+    static const int sdiv = getenv("RFN_WGRAD_SPLIT") ? atoi(getenv("RFN_WGRAD_SPLIT")) : 0;
+    int S = (sdiv > 0 ? sdiv : (WM * WN == 8 ? 256 : 512)) / tiles;
+    if (S > p.n_stages / 4) S = p.n_stages / 4;
     if (S < 1) S = 1;
-    if (S > p.n_stages) S = p.n_stages;
     auto kern = gemm_wgrad_b3_kernel<WM, WN, TM, TN, KP, IMPL>;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
