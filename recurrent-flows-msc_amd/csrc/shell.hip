@@ -241,7 +241,7 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
         // combine); large C -> every thread owns entries e, e+256, ... (plain LDS read-modify-write, single owner)
         if (E <= 256) {
             const int e = t % E, grp = t / E, G_ = 256 / E;
-            if (grp < G_) {
+            if (grp < G_ && blockIdx.y == 0) {
                 const float* gi = G + (e / C) * PBS;
                 const float* yj = Y + (e % C) * PBS;
                 float a = 0.f;
@@ -261,9 +261,12 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
         // gy_j = Σ_i W[i][j] gz_i ; gx_j = gy_j * exp(logs_j) ; gbias_j += Σ gx_j ; glogs_j += Σ gy_j y_j.
         // Thread (px, cg) takes output channels j = cg, cg+ncg, ...: j is wave-uniform (PB >= 64), so W comes through the
         // scalar cache and wave_sum adds over 64 pixels; masked pixels hold zeros.
-        if (blockIdx.y == 0) {
-            for (int j = cg; j < C; j += ncg) {
+        // The output channels are split over blockIdx.y as well (every y-block staged the same tile): at the deep levels a
+        // launch has only a handful of pixel tiles and one block per tile ran C/ncg x C serial steps per thread.
+        {
+            for (int j = cg + ncg * blockIdx.y; j < C; j += ncg * gridDim.y) {
                 float a = 0.f;
+#pragma unroll 8
                 for (int i = 0; i < C; ++i) a = fmaf(Wm[(long)i * C + j], G[i * PBS + px], a);
                 const float gxv = a * expf(logs[j]);
                 if (valid) gx[n * gx_ns + (long)j * HW + p] = gxv;
@@ -277,12 +280,15 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
         }
     }
     __syncthreads();
-    for (int e = blockIdx.y * 256 + t; e < E; e += 256 * gridDim.y) atomicAdd(&gW[e], Wacc[e]);  // owned entries
-    if (blockIdx.y == 0) {
-        for (int c = t; c < C; c += 256) {
-            atomicAdd(&gbias[c], Bacc[c]);
-            atomicAdd(&glogs[c], Lacc[c]);
-        }
+    if (E <= 256) {
+        if (blockIdx.y == 0)
+            for (int e = t; e < E; e += 256) atomicAdd(&gW[e], Wacc[e]);
+    } else {
+        for (int e = blockIdx.y * 256 + t; e < E; e += 256 * gridDim.y) atomicAdd(&gW[e], Wacc[e]);  // owned entries
+    }
+    for (int c = t; c < C; c += 256) {  // channels this y-block did not compute hold zeros
+        if (Bacc[c] != 0.f) atomicAdd(&gbias[c], Bacc[c]);
+        if (Lacc[c] != 0.f) atomicAdd(&glogs[c], Lacc[c]);
     }
 }
 
@@ -392,7 +398,11 @@ extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const floa
     long tot = (long)N * HW;
     int ntiles = (int)((tot + PB - 1) / PB);
     int grid = ntiles < 512 ? ntiles : 512;
+    // blockIdx.y splits the gW entries (C*C > 256) and the output channels of the gx part: aim at <= 2 channels per thread
     int ny = (C * C > 256) ? (C * C + 511) / 512 : 1;
+    const int jpt = C * PB / 256;  // channels per thread without a split
+    if (ny < jpt / 2) ny = jpt / 2;
+    if (ny > 8) ny = 8;
     while (ny > 1 && grid * ny > 2048) ny >>= 1;
     hipLaunchKernelGGL(actnorm_invconv_bwd_kernel, dim3(grid, ny), dim3(256), lds, (hipStream_t)stream, x, x_ns, bias,
                        logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB, ntiles);
