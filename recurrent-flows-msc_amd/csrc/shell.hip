@@ -768,6 +768,35 @@ __global__ void tap_scatter_kernel(const float* __restrict__ g, float* __restric
         Gs[idx] = v;
     }
 }
+// W % 4 == 0: one thread = 4 consecutive pixels of one (frame, tap*C+co, y) row, one 16-byte store, 32-bit index math
+__global__ void tap_scatter_v4_kernel(const float* __restrict__ g, float* __restrict__ Gs, int N, int C, int H, int W) {
+    const int HW4 = H * W / 4, W4 = W / 4;
+    const long HW = (long)H * W, total = (long)N * 9 * C * HW4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const int q = (int)(idx % HW4);
+        const long r = idx / HW4;
+        const int tc = (int)(r % (9 * C));
+        const long n = r / (9 * C);
+        const int t = tc / C, co = tc - t * C;
+        const int y = q / W4, x0 = (q - y * W4) * 4;
+        const int yy = y - (t / 3 - 1), dx = -(t % 3 - 1);  // source = (yy, x + dx)
+        float4 v = {0.f, 0.f, 0.f, 0.f};
+        if (yy >= 0 && yy < H) {
+            const float* src = g + (n * C + co) * HW + (long)yy * W;
+            const float4 c = *reinterpret_cast<const float4*>(src + x0);
+            if (dx == 0) {
+                v = c;
+            } else if (dx < 0) {
+                v.x = x0 > 0 ? src[x0 - 1] : 0.f;
+                v.y = c.x; v.z = c.y; v.w = c.z;
+            } else {
+                v.x = c.y; v.y = c.z; v.z = c.w;
+                v.w = x0 + 4 < W ? src[x0 + 4] : 0.f;
+            }
+        }
+        *reinterpret_cast<float4*>(Gs + idx * 4) = v;
+    }
+}
 extern "C" int rfn_tap_gather_f32(const float* P, const float* bias, const float* logs, float* o, int N, int C, int H,
                                   int W, rfn_stream_t stream) {
     RFN_CHECK_ARG(P && o && N >= 0 && C > 0 && H > 0 && W > 0 && ((bias && logs) || (!bias && !logs)), -1);
@@ -781,6 +810,13 @@ extern "C" int rfn_tap_gather_f32(const float* P, const float* bias, const float
 extern "C" int rfn_tap_scatter_f32(const float* g, float* Gs, int N, int C, int H, int W, rfn_stream_t stream) {
     RFN_CHECK_ARG(g && Gs && N >= 0 && C > 0 && H > 0 && W > 0, -1);
     if (N == 0) return 0;
+    if (W % 4 == 0 && (((uintptr_t)g | (uintptr_t)Gs) & 15) == 0) {
+        long tot4 = (long)N * 9 * C * (H * W / 4);
+        int grid4 = (int)((tot4 + 255) / 256 < 16384 ? (tot4 + 255) / 256 : 16384);
+        hipLaunchKernelGGL(tap_scatter_v4_kernel, dim3(grid4), dim3(256), 0, (hipStream_t)stream, g, Gs, N, C, H, W);
+        RFN_LAUNCH_CHECK();
+        return 0;
+    }
     long tot = (long)N * 9 * C * H * W;
     int grid = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
     hipLaunchKernelGGL(tap_scatter_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, g, Gs, N, C, H, W);
