@@ -685,23 +685,23 @@ __global__ __launch_bounds__(256) void conv_epilogue_bwd_kernel(const float* __r
     if (ep_mode == 1) e = expf(logs[c]);
     if (ep_mode == 2) e = expf(3.f * logs[c]);
     float a_b = 0.f, a_l = 0.f;
-    for (int n = blockIdx.y; n < N; n += gridDim.y) {
-        const float* yp = y ? y + n * y_ns + (long)c * HW : nullptr;
-        const float* gp = gy + n * gy_ns + (long)c * HW;
-        float* up = gu + n * gu_ns + (long)c * HW;
-        for (int p = threadIdx.x; p < HW; p += 256) {
-            float g = gp[p];
-            float yv = yp ? yp[p] : 0.f;
-            float slope = 1.f;
-            if (ep_mode == 1) {
-                if (act == 1) slope = yv > 0.f ? 1.f : 0.f;
-                if (act == 2) slope = yv > 0.f ? 1.f : 0.2f;
-            }
-            float u = g * slope * e;
-            up[p] = u;
-            a_b += u;
-            a_l += g * yv;
+    // (frame, pixel) flattened: at the deep levels a frame has 4 or 16 pixels and a per-frame loop idles the block
+    const long total = (long)N * HW;
+    for (long i = (long)blockIdx.y * 256 + threadIdx.x; i < total; i += (long)gridDim.y * 256) {
+        const long n = i / HW;
+        const int p = (int)(i - n * HW);
+        const long off = (long)c * HW + p;
+        const float g = gy[n * gy_ns + off];
+        const float yv = y ? y[n * y_ns + off] : 0.f;
+        float slope = 1.f;
+        if (ep_mode == 1) {
+            if (act == 1) slope = yv > 0.f ? 1.f : 0.f;
+            if (act == 2) slope = yv > 0.f ? 1.f : 0.2f;
         }
+        const float u = g * slope * e;
+        gu[n * gu_ns + off] = u;
+        a_b += u;
+        a_l += g * yv;
     }
     float tb = block_sum_256(a_b, sm);
     float tl = block_sum_256(a_l, sm);
@@ -718,7 +718,9 @@ extern "C" int rfn_conv_epilogue_bwd_f32(const float* y, long y_ns, const float*
     if (N == 0) return 0;
     int S = 2048 / C;
     if (S < 1) S = 1;
-    if (S > N) S = N;
+    const long per = ((long)N * HW + 1023) / 1024;  // at least ~4 elements per thread
+    if (S > per) S = (int)per;
+    if (S < 1) S = 1;
     hipLaunchKernelGGL(conv_epilogue_bwd_kernel, dim3(C, S), dim3(256), 0, (hipStream_t)stream, y, y_ns, gy, gy_ns, gu,
                        gu_ns, logs, gb, gl, N, C, HW, ep_mode, act);
     RFN_LAUNCH_CHECK();
