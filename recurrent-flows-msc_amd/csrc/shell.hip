@@ -122,25 +122,31 @@ __global__ __launch_bounds__(256) void actnorm_invconv_kernel(const float* __res
                                                               const float* __restrict__ Wm, float* __restrict__ z,
                                                               long z_ns, int N, int C, int HW, int PB) {
     extern __shared__ float lds[];  // [C][PB]
-    const long q = (long)blockIdx.x * PB + threadIdx.x;
-    const bool valid = threadIdx.x < PB && q < (long)N * HW;
+    // thread = (pixel px of the block, channel group ig): all 256 threads stage and compute whatever PB is -- at the deep
+    // levels (C = 32, 64; a few thousand pixels) PB shrinks to 32 so that the launch still has tens of blocks and a
+    // thread forms C/8 outputs instead of all C.
+    const int px = threadIdx.x & (PB - 1), ig = threadIdx.x / PB, NG = 256 / PB;
+    const long q = (long)blockIdx.x * PB + px;
+    const bool valid = q < (long)N * HW;
     int n = 0, p = 0;
     if (valid) {
         n = (int)(q / HW);
         p = (int)(q % HW);
     }
+    const float* src = x + n * x_ns + p;
+    for (int c = ig; c < C; c += NG) {
+        float v = valid ? src[(long)c * HW] : 0.f;
+        if (!REV) v = (v + bias[c]) * expf(logs[c]);
+        lds[c * PB + px] = v;
+    }
+    __syncthreads();
     if (valid) {
-        const float* src = x + n * x_ns + p;
-        for (int c = 0; c < C; ++c) {
-            float v = src[(long)c * HW];
-            if (!REV) v = (v + bias[c]) * expf(logs[c]);
-            lds[c * PB + threadIdx.x] = v;
-        }
         float* dst = z + n * z_ns + p;
-        for (int i = 0; i < C; ++i) {
+        for (int i = ig; i < C; i += NG) {
             float a = 0.f;
             const float* wr = Wm + (long)i * C;
-            for (int j = 0; j < C; ++j) a = fmaf(wr[j], lds[j * PB + threadIdx.x], a);
+#pragma unroll 8
+            for (int j = 0; j < C; ++j) a = fmaf(wr[j], lds[j * PB + px], a);
             if (REV) a = a * expf(-logs[i]) - bias[i];
             dst[(long)i * HW] = a;
         }
@@ -156,12 +162,13 @@ static int shell_pb(int C) {
 static int launch_actnorm_invconv(int rev, const float* x, long x_ns, const float* bias, const float* logs,
                                   const float* Wm, float* z, long z_ns, int N, int C, int HW, hipStream_t s) {
     int PB = shell_pb(C);
+    long tot = (long)N * HW;
+    while (PB > 32 && tot / PB < 256) PB >>= 1;  // few pixels: more, smaller blocks with the channels split over threads
     size_t lds = (size_t)C * PB * 4;
     if (lds > 160 * 1024) {
         rfn_set_error("actnorm_invconv: C=%d too large for the LDS-staged kernel", C);
         return -3;
     }
-    long tot = (long)N * HW;
     int grid = (int)((tot + PB - 1) / PB);
     if (rev) {
         if (lds > 65536)
