@@ -591,6 +591,182 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p, con
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------ weight-stationary 3x3
+// The coupling net's FIRST convolution at the shallow levels (z1 | condition -> Hd: 18 -> 256 on 622 592 pixels at level
+// 0): K = 9 * Cin is tiny, the output (637 MB) is everything.  The generic kernel pads every tap to 16-channel chunks
+// (18 -> 32: 44 % wasted MFMAs), re-stages a weight chunk per 128 pixels and runs four cout blocks per pixel tile.
+// Here the K dimension is the dense list of (tap, 8-channel unit) pairs (27 units for Cin <= 24), the 256 x K weights
+// live in registers (8 waves x 32 output channels), and one persistent workgroup per CU walks 32-pixel tiles whose
+// haloed input image (<= 102 positions x NG units) is double-buffered in LDS.
+template <int NG, int PT>
+__global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, const int n_tiles, const int tw_shift,
+                                                         const int tpf_shift, const int wt_shift) {
+    constexpr int NU = 9 * NG, NSTEPS = (NU + 1) / 2;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    const int TW = 1 << tw_shift, TH = (32 * PT) >> tw_shift;  // PT independent 32-pixel accumulator tiles per step
+    const int IMGW = TW + 2, IMG = IMGW * (TH + 2);
+    const int IMGP = (IMG + 3) & ~3;
+    bf16x8* Bs = reinterpret_cast<bf16x8*>(lds_raw);                        // [2 buffers][plane][NG][IMGP]
+    float* ep = reinterpret_cast<float*>(Bs + 2 * 2 * NG * IMGP);           // [2][256]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int HW = p.H * p.W, Cin = p.C1 + p.C2;
+    const int co_base = blockIdx.y * 256 + wave * 32;
+
+    // weights -> registers: k-step s covers units 2s (lanes 0-31) and 2s+1 (lanes 32-63); unit u = (tap u / NG, group
+    // u % NG) sits in the packed buffer at (((c16*9 + tap)*2 + plane)*2 + g)*CoutP + co with c16 = group/2, g = group%2
+    bf16x8 wh[NSTEPS], wl[NSTEPS];
+    {
+        const bf16x8* wp = reinterpret_cast<const bf16x8*>(p.wpk) + co_base + l31;
+        const bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+            const int u = 2 * s + kk;
+            const bool ok = u < NU && (u % NG) / 2 < p.Cin8;
+            const int uc = ok ? u : 0;
+            const int tap = uc / NG, grp = uc % NG;
+            const long base = (long)(((grp / 2) * 9 + tap) * 2) * 2 + (grp & 1);
+            const bf16x8 h = wp[(base + 0) * p.CoutP];
+            const bf16x8 l = wp[(base + 2) * p.CoutP];
+            wh[s] = ok ? h : z;
+            wl[s] = ok ? l : z;
+        }
+    }
+    if (p.ep_mode != 0) {
+        for (int c = tid; c < 256; c += 512) {
+            const int co = blockIdx.y * 256 + c;
+            float e0 = 0.f, e1 = 1.f;
+            if (co < p.Cout) {
+                e0 = p.p0[co];
+                if (p.ep_mode == 1) e1 = expf(p.p1[co]);
+                if (p.ep_mode == 2) e1 = expf(3.f * p.p1[co]);
+            }
+            ep[c] = e0;
+            ep[256 + c] = e1;
+        }
+    }
+
+    // staging role: one (unit, image position) pair per thread (NG * IMG <= 512)
+    const bool srole = tid < NG * IMG;
+    const int sg = srole ? tid / IMG : 0, spos = srole ? tid - sg * IMG : 0;
+    const int syy = spos / IMGW, sxx = spos - syy * IMGW;
+    float stg[8];
+    bool sval = false;
+    auto tile_origin = [&](int tile, int& n, int& y0, int& x0) {
+        n = tile >> tpf_shift;
+        const int r = tile & ((1 << tpf_shift) - 1);
+        y0 = (r >> wt_shift) * TH;
+        x0 = (r & ((1 << wt_shift) - 1)) * TW;
+    };
+    auto prefetch = [&](int tile) {
+        int n, y0, x0;
+        tile_origin(tile < n_tiles ? tile : 0, n, y0, x0);
+        const int gy = y0 + syy - 1, gx = x0 + sxx - 1;
+        sval = srole && tile < n_tiles && gy >= 0 && gy < p.H && gx >= 0 && gx < p.W;
+        const long off = sval ? (long)gy * p.W + gx : 0;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const int ch = sg * 8 + c;
+            const int chc = ch < Cin ? ch : 0;
+            const float* src = chc < p.C1 ? p.in1 + (long)n * p.in1_ns + (long)chc * HW
+                                          : p.in2 + (long)n * p.in2_ns + (long)(chc - p.C1) * HW;
+            stg[c] = src[off];
+        }
+    };
+    auto commit = [&](int buf) {
+        if (!srole) return;
+        bf16x8 hi, lo;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            const float v = (sval && sg * 8 + c < Cin) ? stg[c] : 0.f;
+            const __bf16 h = (__bf16)v;
+            hi[c] = h;
+            lo[c] = (__bf16)(v - (float)h);
+        }
+        bf16x8* dst = Bs + (long)buf * 2 * NG * IMGP + spos;
+        dst[(0 * NG + sg) * IMGP] = hi;
+        dst[(1 * NG + sg) * IMGP] = lo;
+    };
+
+    // this lane's pixels inside the tile and their image positions (centre tap)
+    int pcol[PT], prow[PT], pbase[PT];
+#pragma unroll
+    for (int t = 0; t < PT; ++t) {
+        const int px = t * 32 + l31;
+        pcol[t] = px & (TW - 1);
+        prow[t] = px >> tw_shift;
+        pbase[t] = (prow[t] + 1) * IMGW + pcol[t] + 1;
+    }
+    int tile = blockIdx.x, buf = 0;
+    prefetch(tile);
+    for (; tile < n_tiles; tile += gridDim.x, buf ^= 1) {
+        commit(buf);
+        prefetch(tile + gridDim.x);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        const bf16x8* bb = Bs + (long)buf * 2 * NG * IMGP;
+        f32x16 acc[1][PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[0][t][r] = 0.f;
+#pragma unroll
+        for (int s = 0; s < NSTEPS; ++s) {
+            // compile-time unit pair of this k-step; the padding unit past 9*NG reads unit 0 (its weights are zero)
+            const int uA = 2 * s, uB = (2 * s + 1 < NU) ? 2 * s + 1 : 0;
+            const int offA = (uA % NG) * IMGP + (uA / NG / 3 - 1) * IMGW + (uA / NG % 3 - 1);
+            const int offB = (uB % NG) * IMGP + (uB / NG / 3 - 1) * IMGW + (uB / NG % 3 - 1);
+            const int off = kk ? offB : offA;
+#pragma unroll
+            for (int t = 0; t < PT; ++t) {
+                const bf16x8 bh = bb[pbase[t] + off];
+                const bf16x8 bl = bb[NG * IMGP + pbase[t] + off];
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wl[s], bh, acc[0][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s], bl, acc[0][t], 0, 0, 0);
+                acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wh[s], bh, acc[0][t], 0, 0, 0);
+            }
+        }
+        int n, y0, x0;
+        tile_origin(tile, n, y0, x0);
+        int pn[PT], ppix[PT];
+        bool pvalid[PT];
+#pragma unroll
+        for (int t = 0; t < PT; ++t) {
+            pn[t] = n;
+            ppix[t] = (y0 + prow[t]) * p.W + x0 + pcol[t];
+            pvalid[t] = true;
+        }
+        conv_epilogue<1, PT, 256, true>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile);
+    }
+}
+
+static bool conv3x3_ws_eligible(const ConvParams& p, int ks) {
+    static const bool off = getenv("RFN_CONV_WS") && atoi(getenv("RFN_CONV_WS")) == 0;
+    const int Cin = p.C1 + p.C2;
+    const bool pow2 = (p.H & (p.H - 1)) == 0 && (p.W & (p.W - 1)) == 0;
+    return !off && ks == 3 && p.Cout % 256 == 0 && Cin <= 24 && pow2 && p.W >= 8 && (long)p.H * p.W >= 64 &&
+           (long)p.N * p.H * p.W >= 64L * 256 && p.ep_mode >= 0 && p.ep_mode <= 3 && p.cout_split == p.Cout && !p.acc1;
+}
+
+static int launch_conv3x3_ws(ConvParams& p, hipStream_t s) {
+    constexpr int PT = 2;
+    const int TW = p.W < 32 ? p.W : 32, TH = 32 * PT / TW;
+    const int tw_shift = ilog2(TW);
+    const int wt = p.W / TW, ht = p.H / TH;  // tiles per row / column of a frame
+    const int wt_shift = ilog2(wt), tpf_shift = ilog2(wt * ht);
+    const int n_tiles = p.N * wt * ht;
+    const int IMG = (TW + 2) * (TH + 2), IMGP = (IMG + 3) & ~3;
+    constexpr int NG = 3;
+    p.ksplit = 1;
+    const size_t lds = (size_t)2 * 2 * NG * IMGP * 16 + 2 * 256 * 4;
+    auto kern = conv3x3_ws_kernel<NG, PT>;
+    dim3 grid(n_tiles < 256 ? n_tiles : 256, p.Cout / 256);
+    hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p, n_tiles, tw_shift, tpf_shift, wt_shift);
+    return 0;
+}
+
 static bool conv1x1_ws_eligible(int ks, int Cin, int C2, int Cout, long npix) {
     static const bool off = getenv("RFN_CONV_WS") && atoi(getenv("RFN_CONV_WS")) == 0;
     return !off && ks == 1 && C2 == 0 && Cout % 256 == 0 && Cin > 128 && Cin <= 256 && npix >= 64L * 256;
@@ -616,6 +792,7 @@ static int dispatch_conv_b3(ConvParams& p, int ks, hipStream_t s) {
     const bool few_px = (long)N * H * W * ((Cout + 127) / 128) < 256L * 128;
     int rc;
     if (conv1x1_ws_eligible(ks, p.C1 + p.C2, p.C2, Cout, (long)N * H * W)) return launch_conv1x1_ws(p, s);
+    if (conv3x3_ws_eligible(p, ks)) return launch_conv3x3_ws(p, s);
     if (ks == 3) {
         if (Cout <= 32)
             rc = launch_conv_b3<3, 1, 4, 1, 1, 16>(p, s);   // 32 co x 128 px

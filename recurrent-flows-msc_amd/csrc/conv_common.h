@@ -50,14 +50,16 @@ __device__ __forceinline__ float half_wave_sum_dpp(float v) {
 
 // Epilogue shared by the fp32 and the bf16x3 kernels (the C/D register layout of the 32x32 MFMA tile does not depend
 // on the input dtype): per-channel affine + activation, bounds, output split over two tensors, accumulate / atomic.
-template <int TCO, int TPX, int BCO>
+// FASTONLY: the caller guarantees full cout tiles, one output tensor, no accumulate / split-K and ep_mode <= 3 -- only the
+// straight store path is instantiated (the weight-stationary kernels have no registers to spare for the others).
+template <int TCO, int TPX, int BCO, bool FASTONLY = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TCO][TPX], const float* ep,
                                               const int co_base, const int wco, const int kk, const int HW,
                                               const int (&pn)[TPX], const int (&ppix)[TPX],
                                               const bool (&pvalid)[TPX], const int prow = 0) {
     const int cl_base = wco * (32 * TCO) + 4 * kk;  // channel index inside the block for (a=0, r=0)
-    const bool fast = (co_base + 32 * TCO <= p.Cout) && (p.cout_split == p.Cout);  // wave-uniform
-    if (p.ep_mode == 4) {
+    const bool fast = FASTONLY || ((co_base + 32 * TCO <= p.Cout) && (p.cout_split == p.Cout));  // wave-uniform
+    if (!FASTONLY && p.ep_mode == 4) {
         // g = this conv's result = grad wrt y = act((u+b)*exp(l)).  Emit gu = g*act'(y)*exp(l) (what the weight- and
         // data-gradient of the producer conv consume) and this wave's per-channel Σ gu (-> grad b) and Σ g*y (-> grad l),
         // so the separate elementwise+reduction pass over the 256-channel hidden tensors disappears.  Host guarantees
@@ -134,7 +136,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     }
                     if (pvalid[t]) {
                         float* dst = obase[t] + (long)cidx * HW;
-                        if (p.ksplit > 1) {
+                        if (FASTONLY) {
+                            *dst = v;
+                        } else if (p.ksplit > 1) {
                             atomicAdd(dst, v);
                         } else {
                             if (p.acc1) v += *dst;
@@ -146,6 +150,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
         }
         return;
     }
+    if (FASTONLY) return;
     // general path: ragged Cout and/or output split over two tensors
 #pragma unroll
     for (int a = 0; a < TCO; ++a) {

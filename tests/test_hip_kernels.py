@@ -112,6 +112,9 @@ CONV_CASES = [
     (6, 100, 0, 200, 4, 4, 1),   # few-pixel 1x1, split-K
     (70, 256, 0, 256, 16, 16, 1),   # weight-stationary 1x1 kernel (>= 16384 pixels, Cout 256, 128 < Cin <= 256)
     (131, 200, 0, 256, 12, 12, 1),  # same kernel: Cin not a multiple of 16, non power-of-two map, ragged last tile
+    (20, 2, 16, 256, 32, 32, 3),    # weight-stationary 3x3 kernel (Cin <= 24, Cout 256, >= 16384 pixels): level-0 conv1
+    (70, 4, 14, 256, 16, 16, 3),    # same kernel, 2 x 16 pixel tiles
+    (300, 10, 0, 256, 8, 8, 3),     # same kernel, 4 x 8 pixel tiles, single source, Cin not a multiple of 8
 ]
 
 
