@@ -746,25 +746,32 @@ static bool conv3x3_ws_eligible(const ConvParams& p, int ks) {
     static const bool off = getenv("RFN_CONV_WS") && atoi(getenv("RFN_CONV_WS")) == 0;
     const int Cin = p.C1 + p.C2;
     const bool pow2 = (p.H & (p.H - 1)) == 0 && (p.W & (p.W - 1)) == 0;
-    return !off && ks == 3 && p.Cout % 256 == 0 && Cin <= 24 && pow2 && p.W >= 8 && (long)p.H * p.W >= 64 &&
+    return !off && ks == 3 && p.Cout % 256 == 0 && Cin <= 40 && pow2 && p.W >= 8 && (long)p.H * p.W >= 64 &&
            (long)p.N * p.H * p.W >= 64L * 256 && p.ep_mode >= 0 && p.ep_mode <= 3 && p.cout_split == p.Cout && !p.acc1;
 }
 
-static int launch_conv3x3_ws(ConvParams& p, hipStream_t s) {
-    constexpr int PT = 2;
+template <int NG, int PT>
+static int launch_conv3x3_ws_t(ConvParams& p, hipStream_t s) {
     const int TW = p.W < 32 ? p.W : 32, TH = 32 * PT / TW;
     const int tw_shift = ilog2(TW);
     const int wt = p.W / TW, ht = p.H / TH;  // tiles per row / column of a frame
     const int wt_shift = ilog2(wt), tpf_shift = ilog2(wt * ht);
     const int n_tiles = p.N * wt * ht;
     const int IMG = (TW + 2) * (TH + 2), IMGP = (IMG + 3) & ~3;
-    constexpr int NG = 3;
+    if (NG * IMG > 512) {
+        rfn_set_error("conv3x3_ws: %d staging items", NG * IMG);
+        return -8;
+    }
     p.ksplit = 1;
     const size_t lds = (size_t)2 * 2 * NG * IMGP * 16 + 2 * 256 * 4;
     auto kern = conv3x3_ws_kernel<NG, PT>;
     dim3 grid(n_tiles < 256 ? n_tiles : 256, p.Cout / 256);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p, n_tiles, tw_shift, tpf_shift, wt_shift);
     return 0;
+}
+static int launch_conv3x3_ws(ConvParams& p, hipStream_t s) {
+    // Cin <= 24: 27 units (112 weight registers), two accumulator tiles per step; Cin <= 40: 45 units (184), one
+    return p.C1 + p.C2 <= 24 ? launch_conv3x3_ws_t<3, 2>(p, s) : launch_conv3x3_ws_t<5, 1>(p, s);
 }
 
 static bool conv1x1_ws_eligible(int ks, int Cin, int C2, int Cout, long npix) {

@@ -115,6 +115,7 @@ CONV_CASES = [
     (20, 2, 16, 256, 32, 32, 3),    # weight-stationary 3x3 kernel (Cin <= 24, Cout 256, >= 16384 pixels): level-0 conv1
     (70, 4, 14, 256, 16, 16, 3),    # same kernel, 2 x 16 pixel tiles
     (300, 10, 0, 256, 8, 8, 3),     # same kernel, 4 x 8 pixel tiles, single source, Cin not a multiple of 8
+    (70, 4, 32, 256, 16, 16, 3),    # same kernel, 45-unit variant (24 < Cin <= 40): level-1 conv1
 ]
 
 
