@@ -393,8 +393,11 @@ static int dispatch_conv_b3(ConvParams& p, int ks, hipStream_t s);
 
 // number of partial-sum rows rfn_conv2d_dgrad_act_bf16x3 writes for (N,H,W,ks,Cout): pixel tiles x waves along pixels
 static bool conv1x1_ws_eligible(int ks, int Cin, int C2, int Cout, long npix);
+static bool conv3x3_ws_rows(int N, int H, int W, int ks, int Cout, int Cin, int* rows);
 extern "C" int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout, int Cin) {
     if (conv1x1_ws_eligible(ks, Cin, 0, Cout, (long)N * H * W)) return (int)(((long)N * H * W + 31) / 32);
+    int ws3_rows = 0;
+    if (conv3x3_ws_rows(N, H, W, ks, Cout, Cin, &ws3_rows)) return ws3_rows;
     ConvParams p;
     memset(&p, 0, sizeof(p));
     p.N = N; p.H = H; p.W = W; p.Cout = Cout;
@@ -599,7 +602,7 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p, con
 // Here the K dimension is the dense list of (tap, 8-channel unit) pairs (27 units for Cin <= 24), the 256 x K weights
 // live in registers (8 waves x 32 output channels), and one persistent workgroup per CU walks 32-pixel tiles whose
 // haloed input image (<= 102 positions x NG units) is double-buffered in LDS.
-template <int NG, int PT>
+template <int NG, int PT, bool FASTEP = true>
 __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, const int n_tiles, const int tw_shift,
                                                          const int tpf_shift, const int wt_shift) {
     constexpr int NU = 9 * NG, NSTEPS = (NU + 1) / 2;
@@ -639,8 +642,8 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
             const int co = blockIdx.y * 256 + c;
             float e0 = 0.f, e1 = 1.f;
             if (co < p.Cout) {
-                e0 = p.p0[co];
-                if (p.ep_mode == 1) e1 = expf(p.p1[co]);
+                if (p.ep_mode != 4) e0 = p.p0[co];
+                if (p.ep_mode == 1 || p.ep_mode == 4) e1 = expf(p.p1[co]);
                 if (p.ep_mode == 2) e1 = expf(3.f * p.p1[co]);
             }
             ep[c] = e0;
@@ -738,7 +741,7 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
             ppix[t] = (y0 + prow[t]) * p.W + x0 + pcol[t];
             pvalid[t] = true;
         }
-        conv_epilogue<1, PT, 256, true>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile);
+        conv_epilogue<1, PT, 256, FASTEP>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile);
     }
 }
 
@@ -746,11 +749,22 @@ static bool conv3x3_ws_eligible(const ConvParams& p, int ks) {
     static const bool off = getenv("RFN_CONV_WS") && atoi(getenv("RFN_CONV_WS")) == 0;
     const int Cin = p.C1 + p.C2;
     const bool pow2 = (p.H & (p.H - 1)) == 0 && (p.W & (p.W - 1)) == 0;
-    return !off && ks == 3 && p.Cout % 256 == 0 && Cin <= 40 && pow2 && p.W >= 8 && (long)p.H * p.W >= 64 &&
-           (long)p.N * p.H * p.W >= 64L * 256 && p.ep_mode >= 0 && p.ep_mode <= 3 && p.cout_split == p.Cout && !p.acc1;
+    const bool shape = !off && ks == 3 && p.Cout % 256 == 0 && pow2 && p.W >= 8 && (long)p.H * p.W >= 64 &&
+                       (long)p.N * p.H * p.W >= 64L * 256 && p.cout_split == p.Cout && !p.acc1;
+    if (p.ep_mode == 4) return shape && Cin <= 8 && p.C2 == 0;  // fused activation backward: 9-unit variant only
+    return shape && Cin <= 40 && p.ep_mode >= 0 && p.ep_mode <= 3;
+}
+// rows of partial sums the ep_mode-4 variant writes: one per 64-pixel tile
+static bool conv3x3_ws_rows(int N, int H, int W, int ks, int Cout, int Cin, int* rows) {
+    ConvParams p;
+    memset(&p, 0, sizeof(p));
+    p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.cout_split = Cout; p.C1 = Cin; p.ep_mode = 4;
+    if (!conv3x3_ws_eligible(p, ks)) return false;
+    *rows = (int)((long)N * H * W / 64);
+    return true;
 }
 
-template <int NG, int PT>
+template <int NG, int PT, bool FASTEP = true>
 static int launch_conv3x3_ws_t(ConvParams& p, hipStream_t s) {
     const int TW = p.W < 32 ? p.W : 32, TH = 32 * PT / TW;
     const int tw_shift = ilog2(TW);
@@ -764,13 +778,14 @@ static int launch_conv3x3_ws_t(ConvParams& p, hipStream_t s) {
     }
     p.ksplit = 1;
     const size_t lds = (size_t)2 * 2 * NG * IMGP * 16 + 2 * 256 * 4;
-    auto kern = conv3x3_ws_kernel<NG, PT>;
+    auto kern = conv3x3_ws_kernel<NG, PT, FASTEP>;
     dim3 grid(n_tiles < 256 ? n_tiles : 256, p.Cout / 256);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p, n_tiles, tw_shift, tpf_shift, wt_shift);
     return 0;
 }
 static int launch_conv3x3_ws(ConvParams& p, hipStream_t s) {
     // Cin <= 24: 27 units (112 weight registers), two accumulator tiles per step; Cin <= 40: 45 units (184), one
+    if (p.ep_mode == 4) return launch_conv3x3_ws_t<1, 2, false>(p, s);
     return p.C1 + p.C2 <= 24 ? launch_conv3x3_ws_t<3, 2>(p, s) : launch_conv3x3_ws_t<5, 1>(p, s);
 }
 

@@ -136,7 +136,7 @@ def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks):
     part = torch.empty((rows, Cout, 2), device=gin.device, dtype=torch.float32)
     L.call("rfn_conv2d_dgrad_act_bf16x3", gp, _l(gns), _i(Cin), L.dev(wpk_flip), yp, _l(yns), L.dev(logs), _i(act), up,
            _l(uns), L.dev(part), _i(Cout), _i(N), _i(H), _i(W), _i(ks),
-           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W, Cin) + "+actbwd", 2.0 * N * H * W * Cin * Cout * ks * ks,
+           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W, Cin, (H, W), True, True) + "+actbwd", 2.0 * N * H * W * Cin * Cout * ks * ks,
                  "N%d %d->%d %dx%d k%d dgrad+actbwd" % (N, Cin, Cout, H, W, ks),
                  4.0 * (N * H * W * (Cin + 2 * Cout) + Cin * Cout * ks * ks)))
     sums = part.sum(0)
@@ -190,7 +190,7 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
            L.dev(wpk), o1p, _l(o1ns), o2p,
            _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W), _i(ks),
            _i(ep_mode), L.dev(p0), L.dev(p1), _i(act),
-           meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W, (C1 + C2) if C2 == 0 else None) if b3 else conv_kernel_name(Cout, ks, N * H * W),
+           meta=("conv", _fwd_b3_name(Cout, ks, N, H, W, C1, C2, cout_split, acc1, acc2, ep_mode) if b3 else conv_kernel_name(Cout, ks, N * H * W),
                  2.0 * N * H * W * (C1 + C2) * Cout * ks * ks,
                  "N%d %d+%d->%d %dx%d k%d ep%d%s" % (N, C1, C2, Cout, H, W, ks, ep_mode,
                                                   "" if cout_split == Cout else " split"),
@@ -198,9 +198,27 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
     return out1
 
 
-def conv_b3_kernel_name(Cout, ks, npix=1 << 30, Cin=None):
-    """the template instantiation rfn_conv2d_fwd_bf16x3 dispatches to (mirrors csrc/conv_bf16x3.hip)"""
+def _fwd_b3_name(Cout, ks, N, H, W, C1, C2, cout_split, acc1, acc2, ep_mode):
+    plain = cout_split == Cout and not acc1 and not acc2 and ep_mode <= 3
+    if ks == 1:
+        return conv_b3_kernel_name(Cout, ks, N * H * W, (C1 + C2) if C2 == 0 else None)
+    return conv_b3_kernel_name(Cout, ks, N * H * W, C1 + C2, (H, W), plain, False)
+
+
+def conv_b3_kernel_name(Cout, ks, npix=1 << 30, Cin=None, hw=None, plain=True, actbwd=False):
+    """the template instantiation rfn_conv2d_fwd_bf16x3 dispatches to (mirrors csrc/conv_bf16x3.hip) -- for profiling
+    labels.  Cin = total input channels when the input is ONE tensor (else None); hw = (H, W); plain = single output
+    tensor, no accumulate."""
     few = npix * ((Cout + 127) // 128) < 256 * 128
+    ws_on = os.environ.get("RFN_CONV_WS") != "0"
+    if ks == 3 and ws_on and hw is not None and plain and Cout % 256 == 0 and npix >= 64 * 256:
+        H, W = hw
+        if H & (H - 1) == 0 and W & (W - 1) == 0 and W >= 8 and H * W >= 64:
+            cin = Cin if isinstance(Cin, int) else None
+            if actbwd and cin is not None and cin <= 8:
+                return "conv3x3_ws_kernel<1,2,0>"
+            if not actbwd and Cin is not None and Cin <= 40:
+                return "conv3x3_ws_kernel<%s>" % ("3,2,1" if Cin <= 24 else "5,1,1")
     if ks == 3:
         cfg = "1,4,1,1" if Cout <= 32 else ("2,2,1,1" if few else "2,2,1,2")
         return "conv_b3_kernel<3,%s,16>" % cfg
