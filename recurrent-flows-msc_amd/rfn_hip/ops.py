@@ -139,8 +139,8 @@ def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks):
            meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W, Cin, (H, W), True, True) + "+actbwd", 2.0 * N * H * W * Cin * Cout * ks * ks,
                  "N%d %d->%d %dx%d k%d dgrad+actbwd" % (N, Cin, Cout, H, W, ks),
                  4.0 * (N * H * W * (Cin + 2 * Cout) + Cin * Cout * ks * ks)))
-    sums = part.sum(0)
-    return gu, sums[:, 0], sums[:, 1]
+    sums = part.sum(0).t().contiguous()  # [2, Cout]: contiguous rows, which AccumulateGrad can keep without a copy
+    return gu, sums[0], sums[1]
 
 
 class PackPlan:
@@ -646,6 +646,7 @@ class LatentStepFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, enc, pri, eps_p, eps_q, res_q):
+        ctx.set_materialize_grads(False)  # unused outputs (enc_mean / enc_std without overshooting) arrive as None
         B = int(enc.shape[0])
         shp = (B, enc.shape[1] // 2) + tuple(enc.shape[2:])
         ZHW = 1
