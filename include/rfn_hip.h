@@ -212,6 +212,16 @@ int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float slope_in, co
                               const float* add, int act_out, float slope_out, float* out, float* a_out, int B, int K, int N,
                               int HW, rfn_stream_t stream);
 
+/* The same dense product behind the interface of rfn_conv2d_fwd_bf16x3 (ks = 3 implied): N frames of an H x W <= 16
+ * map, two-source input, ep_mode 0-3, output channels split at cout_split, out1 optionally accumulated.  `packed` from
+ * rfn_smallmap_pack_bf16x3 of the [Cout][C1+C2][3][3] weight (transpose 0), or transpose 1 of the FORWARD weight for a
+ * data gradient.  (C1*H*W) % 8 == 0 and ((C1+C2)*H*W) % 8 == 0.  Used for the coupling convolutions of the two deepest
+ * flow levels, where a launch is a few thousand pixels against megabytes of weights. */
+int rfn_smallmap_conv_bf16x3(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                             const float* packed, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                             int cout_split, int acc1, int N, int H, int W, int ep_mode, const float* p0,
+                             const float* p1, int act, rfn_stream_t stream);
+
 /* ---- a9  ConvLSTMLayer.forward gate update  (Utils/modules.py:370-377): cc = conv output [N,4*Hc,HW] in gate order
  * i,f,o,g;  i=σ(cc_i+Wci∘c) f=σ(cc_f+Wcf∘c) g=tanh(cc_g) c'=f∘c+i∘g o=σ(cc_o+Wco∘c') h'=o∘tanh(c').
  * Wci/Wcf/Wco [Hc*HW] may be NULL (== 0, which is what the reference trains with).  gates [N,4*Hc,HW] receives the

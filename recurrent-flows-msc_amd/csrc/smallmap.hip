@@ -87,6 +87,16 @@ struct SmallmapParams {
     float* out;           // [B][N]
     float* a_out;         // optional [B][K]: the scaled a (pre-activation gradient, kept for the weight gradient)
     int B, K, N, HW, KS;
+    // convolution form (rfn_smallmap_conv_bf16x3): rows are frames of one or two NCHW tensors with frame strides, the
+    // epilogue is the convolution kernels' (ep_mode 1: (v+p0)*exp(p1) then act; 2: (v+p0)*exp(3 p1); 3: v+p0), the output
+    // channels may be split over two tensors and out1 may accumulate
+    long a_ns, a2_ns, out_ns, out2_ns;  // row (frame) strides in floats
+    const float* a2;                    // second source: columns K1 .. K-1
+    int K1;
+    int ep_mode, act, nsplit, acc1;     // nsplit = columns that go to out (the rest to out2)
+    const float* p0;
+    const float* p1;
+    float* out2;
 };
 
 constexpr int SM_WAVES = 8;
@@ -98,7 +108,8 @@ __global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const Sma
     const int tile = blockIdx.x, m0 = blockIdx.y * 32;
     const int m = m0 + l31;
     const bool mok = m < p.B;
-    const float* arow = p.a + (long)(mok ? m : 0) * p.K;
+    const float* arow = p.a + (long)(mok ? m : 0) * p.a_ns;
+    const float* a2row = p.a2 ? p.a2 + (long)(mok ? m : 0) * p.a2_ns : arow;
     const float* yrow = p.y ? p.y + (long)(mok ? m : 0) * p.K : nullptr;
     float* aorow = (p.a_out && tile == 0 && mok) ? p.a_out + (long)m * p.K : nullptr;
     const bf16x8* wp = p.packed + (long)tile * p.KS * 2 * 64 + lane;
@@ -110,7 +121,8 @@ __global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const Sma
     for (int ks = wave; ks < p.KS; ks += SM_WAVES) {
         const int k = ks * 16 + kg * 8;
         const bool kok = mok && k < p.K;  // K % 8 == 0 (checked on the host): a group is all in or all out
-        const float* ap = arow + (kok ? k : 0);
+        const int kc = kok ? k : 0;
+        const float* ap = kc < p.K1 ? arow + kc : a2row + (kc - p.K1);  // K1 % 8 == 0: a group never straddles
         float4 v0 = *reinterpret_cast<const float4*>(ap);
         float4 v1 = *reinterpret_cast<const float4*>(ap + 4);
         const bf16x8 bh = wp[(long)(ks * 2 + 0) * 64];
@@ -151,10 +163,26 @@ __global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const Sma
         for (int w = 0; w < SM_WAVES; ++w) s += red[w][mm][nn];
         const int n = tile * 32 + nn, row = m0 + mm;
         if (row < p.B && n < p.N) {
-            if (p.bias) s += p.bias[n / p.HW];
+            const int c = n / p.HW;
+            if (p.bias) s += p.bias[c];
             if (p.add) s += p.add[(long)row * p.N + n];
             if (p.act_out) s = s > 0.f ? s : s * p.slope_out;
-            p.out[(long)row * p.N + n] = s;
+            if (p.ep_mode != 0) {
+                s += p.p0[c];
+                if (p.ep_mode == 1) s *= expf(p.p1[c]);
+                if (p.ep_mode == 2) s *= expf(3.f * p.p1[c]);
+                if (p.ep_mode == 1) {
+                    if (p.act == 1) s = s > 0.f ? s : 0.f;
+                    if (p.act == 2) s = s > 0.f ? s : 0.2f * s;
+                }
+            }
+            if (n < p.nsplit) {
+                float* dst = p.out + (long)row * p.out_ns + n;
+                if (p.acc1) s += *dst;
+                *dst = s;
+            } else {
+                p.out2[(long)row * p.out2_ns + (n - p.nsplit)] = s;
+            }
         }
     }
 }
@@ -171,7 +199,36 @@ extern "C" int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float s
     p.a = a; p.y = y; p.slope_in = slope_in; p.packed = reinterpret_cast<const bf16x8*>(packed); p.bias = bias; p.add = add;
     p.act_out = act_out; p.slope_out = slope_out; p.out = out; p.a_out = a_out;
     p.B = B; p.K = K; p.N = N; p.HW = HW; p.KS = (K + 15) / 16;
+    p.a_ns = K; p.K1 = K; p.out_ns = N; p.nsplit = N;
     dim3 grid((N + 31) / 32, (B + 31) / 32);
+    hipLaunchKernelGGL(smallmap_dense_kernel, grid, dim3(64 * SM_WAVES), 0, (hipStream_t)stream, p);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// The same product behind the convolution entry point's interface (rfn_conv2d_fwd_bf16x3 without ks): 3x3 / pad 1 on an
+// H x W <= 16 map of N frames, two-source input, the conv epilogues 0-3, output channels split at cout_split, out1
+// optionally accumulated.  `packed` from rfn_smallmap_pack_bf16x3(w[Cout][C1+C2][3][3], transpose 0) -- or transpose 1
+// of the forward weight for a data gradient, in which case (C1+C2) is the forward Cout and Cout the forward Cin.
+extern "C" int rfn_smallmap_conv_bf16x3(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                                        const float* packed, float* out1, long out1_ns, float* out2, long out2_ns,
+                                        int Cout, int cout_split, int acc1, int N, int H, int W, int ep_mode,
+                                        const float* p0, const float* p1, int act, rfn_stream_t stream) {
+    const int HW = H * W;
+    RFN_CHECK_ARG(in1 && packed && out1 && C1 > 0 && C2 >= 0 && (C2 == 0 || in2) && Cout > 0 && N >= 0 && HW > 0 && HW <= 16, -1);
+    RFN_CHECK_ARG(cout_split > 0 && cout_split <= Cout && (cout_split == Cout || out2), -2);
+    RFN_CHECK_ARG(ep_mode >= 0 && ep_mode <= 3 && (ep_mode == 0 || p0) && ((ep_mode != 1 && ep_mode != 2) || p1), -3);
+    RFN_CHECK_ARG((C1 * HW) % 8 == 0 && ((C1 + C2) * HW) % 8 == 0 && in1_ns % 4 == 0 && (C2 == 0 || in2_ns % 4 == 0), -4);
+    RFN_CHECK_ARG((((uintptr_t)in1 | (uintptr_t)packed | (uintptr_t)(C2 ? in2 : in1)) & 15) == 0, -5);
+    if (N == 0) return 0;
+    SmallmapParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = in1; p.a_ns = in1_ns; p.a2 = C2 ? in2 : nullptr; p.a2_ns = in2_ns; p.K1 = C1 * HW;
+    p.packed = reinterpret_cast<const bf16x8*>(packed);
+    p.out = out1; p.out_ns = out1_ns; p.out2 = out2; p.out2_ns = out2_ns; p.nsplit = cout_split * HW; p.acc1 = acc1;
+    p.ep_mode = ep_mode; p.act = act; p.p0 = p0; p.p1 = p1;
+    p.B = N; p.K = (C1 + C2) * HW; p.N = Cout * HW; p.HW = HW; p.KS = (p.K + 15) / 16;
+    dim3 grid((p.N + 31) / 32, (N + 31) / 32);
     hipLaunchKernelGGL(smallmap_dense_kernel, grid, dim3(64 * SM_WAVES), 0, (hipStream_t)stream, p);
     RFN_LAUNCH_CHECK();
     return 0;

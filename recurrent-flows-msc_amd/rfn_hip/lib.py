@@ -62,6 +62,8 @@ SIGNATURES = {
     "rfn_smallmap_pack_bf16x3": [_c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_s],
     "rfn_smallmap_dense_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i,
                                   _c_i, _c_i, _c_i, _c_s],
+    "rfn_smallmap_conv_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
+                                 _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
     "rfn_convlstm_gates_fwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,
                                    _c_s],
     "rfn_convlstm_gates_bwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f,

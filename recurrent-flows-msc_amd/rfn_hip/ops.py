@@ -482,11 +482,23 @@ class GlowStepFn(torch.autograd.Function):
         cin2 = cond if cond.shape[1] > 0 else None
         pk = packs if packs is not None else (None,) * 6
         ctx.packs = packs
-        h1 = conv2d_raw(z1, cin2, pk[0] if pk[0] is not None else pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b),
-                        f(n1l), act)
+        # the two deepest levels (H*W <= 16): a launch is a few thousand pixels against megabytes of weights, the
+        # 3x3 convolutions go through the dense small-map kernels
+        Cc_ = 0 if cin2 is None else int(cin2.shape[1])
+        k33 = int(w1.shape[2]) == 3 and int(w3.shape[2]) == 3
+        dense = k33 and smallmap_conv_ok(H, W, Ch, Cc_, Hd, N)
+        dense3 = k33 and smallmap_conv_ok(H, W, Hd, 0, C, N) and not zeros_conv_uses_taps(w3)
+        if dense:
+            h1 = smallmap_conv(z1, cin2, smallmap_pack(w1, H, W, False), Hd, 1, f(n1b), f(n1l), act)
+        else:
+            h1 = conv2d_raw(z1, cin2, pk[0] if pk[0] is not None else pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b),
+                            f(n1l), act)
         h2 = conv2d_raw(h1, None, pk[2] if pk[2] is not None else pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b),
                         f(n2l), act)
-        o = zeros_conv_fwd(h2, w3, f(b3), f(l3), pk[4])
+        if dense3:
+            o = smallmap_conv(h2, None, smallmap_pack(w3, H, W, False), C, 2, f(b3), f(l3), 0)
+        else:
+            o = zeros_conv_fwd(h2, w3, f(b3), f(l3), pk[4])
         dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
         affine_coupling_(out, o, f(scale), f(scale_shift), dlogdet, clamp_type, False)
         ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o)
@@ -547,9 +559,13 @@ class GlowStepFn(torch.autograd.Function):
         has_cond = cond.shape[1] > 0
         gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
         gcond = torch.empty_like(cond) if has_cond else torch.zeros_like(cond)
-        conv2d_raw(gh1, None, pk[1] if pk[1] is not None else pack_weight(w1, True), Ch + int(cond.shape[1]), k1, 0,
-                   None, None, 0, out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True,
-                   acc2=False)
+        if k1 == 3 and k3 == 3 and smallmap_conv_ok(H, W, Hd, 0, Ch + Cc, N):
+            smallmap_conv(gh1, None, smallmap_pack(w1, H, W, True), Ch + Cc, 0, out1=gz[:, :Ch],
+                          out2=gcond if has_cond else None, cout_split=Ch, acc1=True)
+        else:
+            conv2d_raw(gh1, None, pk[1] if pk[1] is not None else pack_weight(w1, True), Ch + int(cond.shape[1]), k1, 0,
+                       None, None, 0, out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True,
+                       acc2=False)
         # ---- invconv + actnorm bwd
         gx, gW, gab, gal = actnorm_invconv_bwd(x, f(an_bias), f(an_logs), Wm.detach(), gz, arena)
         return (gx, gcond, gW, gab.view(an_bias.shape), gal.view(an_logs.shape), gw1, gn1b.view(1, -1, 1, 1),
@@ -638,6 +654,38 @@ def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slo
            L.dev(addc), _i(0 if slope_out is None else 1), ctypes.c_float(0.0 if slope_out is None else slope_out), L.dev(out),
            L.dev(a_out), _i(B), _i(K), _i(n_channels * HW), _i(HW))
     return (out, a_out) if want_a_out else out
+
+
+def smallmap_conv_ok(H, W, C1, C2, Cout, N):
+    """3x3 conv on a map small enough for the dense kernels (rfn_smallmap_conv_bf16x3), and few enough frames: every
+    32-frame row tile streams the whole dense matrix ((C1+C2)*HW x Cout*HW, on a 4x4 map more than half structural
+    zeros), so the product is only used while that stream stays L2 / Infinity-Cache sized."""
+    HW = H * W
+    stream = -(-N // 32) * (C1 + C2) * HW * Cout * HW
+    return (CONV_PRECISION == "bf16x3" and HW <= 16 and (C1 * HW) % 8 == 0 and ((C1 + C2) * HW) % 8 == 0
+            and stream <= 32 * 1024 * 1024 and os.environ.get("RFN_SMALLMAP_GLOW") != "0")
+
+
+def smallmap_conv(in1, in2, packed, Cout, ep_mode=0, p0=None, p1=None, act=0, out1=None, out2=None, cout_split=None,
+                  acc1=False):
+    """conv2d_raw's contract (3x3, pad 1) on an H*W <= 16 map through the dense split-precision product."""
+    N, C1, H, W = in1.shape
+    C2 = 0 if in2 is None else int(in2.shape[1])
+    if cout_split is None:
+        cout_split = Cout
+    if out1 is None:
+        out1 = torch.empty((N, cout_split, H, W), device=in1.device, dtype=torch.float32)
+    i1p, i1ns = L.frames(in1, "in1")
+    i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
+    o1p, o1ns = L.frames(out1, "out1")
+    o2p, o2ns = (None, 0) if out2 is None else L.frames(out2, "out2")
+    L.call("rfn_smallmap_conv_bf16x3", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(packed), o1p, _l(o1ns), o2p,
+           _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(N), _i(H), _i(W), _i(ep_mode), L.dev(p0),
+           L.dev(p1), _i(act),
+           meta=("conv", "smallmap_dense_kernel", 2.0 * N * H * W * (C1 + C2) * Cout * 9,
+                 "N%d %d+%d->%d %dx%d k3 ep%d dense" % (N, C1, C2, Cout, H, W, ep_mode),
+                 4.0 * (N * H * W * (C1 + C2 + Cout) + (C1 + C2) * Cout * H * W * H * W)))
+    return out1
 
 
 class LatentStepFn(torch.autograd.Function):

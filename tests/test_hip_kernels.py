@@ -266,6 +266,50 @@ def test_smallmap_dense_conv_fwd_bwd(K, B, Cin, Cout, H, W, slope):
     assert relerr(gx, x.grad) < 2e-5
 
 
+@pytest.mark.parametrize("N,C1,C2,Cout,H,W,ep_mode,act,split", [(70, 32, 256, 256, 2, 2, 1, 2, None),
+                                                                 (40, 16, 24, 64, 4, 4, 1, 1, None),
+                                                                 (33, 256, 0, 64, 2, 2, 2, 0, None),
+                                                                 (50, 64, 0, 40, 4, 4, 0, 0, 16),
+                                                                 (5, 6, 2, 10, 2, 4, 3, 0, None)])
+def test_smallmap_conv_interface(K, N, C1, C2, Cout, H, W, ep_mode, act, split):
+    """rfn_smallmap_conv_bf16x3 (dense kernels behind conv2d_raw's contract: two-source input with frame strides, conv
+    epilogues 0-3, split + accumulated outputs) against the reference formulation of Conv2dNorm / Conv2dZeros
+    (glow_modules.py:119-121,139-142) and of a data gradient written into a channel-slice view."""
+    if K.CONV_PRECISION != "bf16x3":
+        pytest.skip("split-precision kernels only")
+    g = torch.Generator().manual_seed(90)
+    big = torch.randn(N, 2 * C1, H, W, generator=g)          # in1 is a channel-slice view, like z1 = x[:, :C/2]
+    x1 = big[:, :C1]
+    x2 = torch.randn(N, C2, H, W, generator=g) if C2 else None
+    w = torch.randn(Cout, C1 + C2, 3, 3, generator=g) / (3 * (C1 + C2) ** 0.5)
+    p0, p1 = torch.randn(Cout, generator=g) * 0.3, torch.randn(Cout, generator=g) * 0.2
+    u = F.conv2d(torch.cat([x1, x2], 1) if C2 else x1, w, None, padding=1)
+    if ep_mode == 1:
+        ref = (u + p0.view(1, -1, 1, 1)) * p1.view(1, -1, 1, 1).exp()
+        ref = O.act_fun(ref, ["none", "relu", "leakyrelu"][act]) if act else ref
+    elif ep_mode == 2:
+        ref = (u + p0.view(1, -1, 1, 1)) * (3 * p1.view(1, -1, 1, 1)).exp()
+    elif ep_mode == 3:
+        ref = u + p0.view(1, -1, 1, 1)
+    else:
+        ref = u
+    pk = K.smallmap_pack(cu(w), H, W, False)
+    bigk = cu(big)
+    kw = dict(ep_mode=ep_mode, p0=cu(p0) if ep_mode else None, p1=cu(p1) if ep_mode in (1, 2) else None, act=act)
+    if split is None:
+        out = K.smallmap_conv(bigk[:, :C1], cu(x2) if C2 else None, pk, Cout, **kw)
+        assert relerr(out, ref) < 3e-5
+    else:
+        base = torch.randn(N, 2 * split, H, W, generator=g)   # out1 = first half of a bigger tensor, accumulated into
+        basek = cu(base)
+        o2 = torch.empty(N, Cout - split, H, W, device="cuda")
+        K.smallmap_conv(bigk[:, :C1], cu(x2) if C2 else None, pk, Cout, out1=basek[:, :split], out2=o2, cout_split=split,
+                        acc1=True, **kw)
+        assert relerr(basek[:, :split], base[:, :split] + ref[:, :split]) < 3e-5
+        assert relerr(basek[:, split:], base[:, split:]) == 0
+        assert relerr(o2, ref[:, split:]) < 3e-5
+
+
 @pytest.mark.parametrize("res_q", [False, True])
 @pytest.mark.parametrize("use", ["all", "kl_only", "no_kl"])
 def test_latent_step_fwd_bwd(K, res_q, use):
