@@ -281,8 +281,12 @@ def main():
             solver.train_step(batches[0])  # first replay outside the timed region
     barrier()
     t0 = time.perf_counter()
+    trace = os.environ.get("RFN_BENCH_TRACE") == "1"
     for i in range(a.steps):
         solver.train_step(batches[i % 2])
+        if trace:
+            torch.cuda.synchronize()
+            print("[bench] rank %d step %d done at +%.3f s" % (rank, i, time.perf_counter() - t0), file=sys.stderr, flush=True)
     barrier()
     dt = time.perf_counter() - t0
     solver.flush_log()

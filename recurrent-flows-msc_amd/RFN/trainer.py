@@ -203,11 +203,25 @@ class Solver(object):
         self._g_out = torch.stack([loss.detach(), kl_free_bit.detach(), kl.detach(), nll.detach()])
 
     def _graphed_step(self, image):
-        self._g_in.copy_(image, non_blocking=True)
-        self._g_beta.fill_(self.beta)
-        self._graph.replay()
-        self.reducer.finish()
-        self.optimizer.step()
+        if os.environ.get("RFN_STEP_TRACE") == "1":  # developer aid: wall time of the phases of a replayed step
+            import time
+            ts = []
+            def mark():
+                torch.cuda.synchronize()
+                ts.append(time.perf_counter())
+            mark(); self._g_in.copy_(image, non_blocking=True); self._g_beta.fill_(self.beta)
+            mark(); self._graph.replay()
+            mark(); self.reducer.finish()
+            mark(); self.optimizer.step()
+            mark()
+            print("[step %d rank %d] copy %.3f replay %.3f reduce %.3f adam %.3f s" % (
+                self.counter, self.rank, ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], ts[4] - ts[3]), flush=True)
+        else:
+            self._g_in.copy_(image, non_blocking=True)
+            self._g_beta.fill_(self.beta)
+            self._graph.replay()
+            self.reducer.finish()
+            self.optimizer.step()
         if self.scheduler_type == "linear":
             self.adjust_learning_rate(self.counter)
         self.counter += 1

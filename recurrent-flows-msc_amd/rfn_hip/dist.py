@@ -70,6 +70,10 @@ class GradBucketReducer:
         b = self.buckets[bi]
         grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
         flat = torch.cat([g.reshape(-1) for g in grads])
+        if flat.is_cuda and dist.get_backend(self.group) == "gloo":
+            # CPU-side collective on device memory (the one-GPU rehearsal of the N>1 path): without this the ranks sharing a
+            # GPU were observed to stall for tens of seconds inside gloo's own stream hand-over
+            torch.cuda.current_stream().synchronize()
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         self._flat[bi] = flat
         self._works.append((bi, work))
@@ -92,15 +96,18 @@ class GradBucketReducer:
             work.wait()
             flat = self._flat[bi]
             flat.div_(self.world)
-            off = 0
+            off, dst, src = 0, [], []
             for p in self.buckets[bi]:
                 n = p.numel()
                 g = flat[off:off + n].view_as(p)
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
-                    p.grad.copy_(g)
+                    dst.append(p.grad)
+                    src.append(g)
                 off += n
+            if dst:
+                torch._foreach_copy_(dst, src)  # one multi-tensor launch per bucket instead of one copy per parameter
             self._flat[bi] = None
         self.reset()
 
