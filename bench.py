@@ -310,6 +310,16 @@ def main():
            "modeled_frames_per_s": a.batch * (a.frames - 1) * a.steps / dt, "bits_per_dim_last_step": bpd,
            "launch_mode": "hipGraph replay (fwd+bwd captured)" if graphed else "eager"}
     if rank == 0 and world == 1:
+        # forward-only rate: RFN.loss under no_grad on the same batch, eager launches
+        with torch.no_grad():
+            xin = solver.preprocess(batches[0])
+            solver.model.loss(xin, 0)
+            torch.cuda.synchronize()
+            tf0 = time.perf_counter()
+            for _ in range(3):
+                solver.model.loss(xin, 0)
+            torch.cuda.synchronize()
+            out["forward_only_frames_per_s"] = a.batch * a.frames * 3 / (time.perf_counter() - tf0)
         if profile:
             roof, table = kernel_roofline(rec, 2)
             out["roofline"] = roof
