@@ -5,6 +5,8 @@
 * VGG_downscaler / VGG_upscaler / SimpleParamNet / NormLayer / ActFun — callers of the hot path:
   ordinary conv/BN stacks kept as PyTorch-ROCm modules, same constructor arguments and parameter names.
 """
+import os
+
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
@@ -84,13 +86,54 @@ def per_step_batchnorm(bn, x, steps):
     return y
 
 
+def _act_code(m):
+    """(code, slope) of an activation module the fused per-step BatchNorm kernels implement, else None"""
+    if isinstance(m, ActFun):
+        m = m.net
+    if isinstance(m, nn.LeakyReLU):
+        return 2, float(m.negative_slope)
+    if isinstance(m, nn.ReLU):
+        return 1, 0.0
+    if isinstance(m, nn.Tanh):
+        return 3, 0.0
+    return None
+
+
+def per_step_batchnorm_act(bn, x, steps, act_code, slope):
+    """per_step_batchnorm fused with the following activation on the HIP kernels (rfn_stepbn_*): no permute copies, one
+    statistics pass and one normalise+activate pass forward, one reduction and one apply pass backward."""
+    y, mean, var = K.StepBatchNormActFn.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, steps,
+                                              float(bn.eps), act_code, slope)
+    if bn.track_running_stats:
+        with torch.no_grad():
+            n = (x.shape[0] // steps) * x.shape[2] * x.shape[3]
+            m = bn.momentum if bn.momentum is not None else 0.1
+            coef = m * (1.0 - m) ** torch.arange(steps - 1, -1, -1, device=x.device, dtype=x.dtype)
+            decay = (1.0 - m) ** steps
+            bn.running_mean.mul_(decay).add_((coef.view(steps, 1) * mean).sum(0))
+            bn.running_var.mul_(decay).add_((coef.view(steps, 1) * var).sum(0) * (n / max(n - 1, 1)))
+            bn.num_batches_tracked += steps
+    return y
+
+
 def run_time_batched(seq, x, steps):
     """run an nn.Sequential on a step-major time-batched tensor, BatchNorm statistics per step."""
-    for m in seq:
+    mods = list(seq)
+    i = 0
+    while i < len(mods):
+        m = mods[i]
         if isinstance(m, NormLayer) and isinstance(m.norm, nn.BatchNorm2d):
-            x = per_step_batchnorm(m.norm, x, steps)
+            bn = m.norm
+            fused = x.is_cuda and bn.training and x.dtype == torch.float32 and os.environ.get("RFN_STEPBN") != "0"
+            if fused:
+                act = _act_code(mods[i + 1]) if i + 1 < len(mods) else None
+                x = per_step_batchnorm_act(bn, x, steps, act[0] if act else 0, act[1] if act else 0.0)
+                i += 2 if act else 1
+                continue
+            x = per_step_batchnorm(bn, x, steps)
         else:
             x = m(x)
+        i += 1
     return x
 
 

@@ -833,6 +833,175 @@ extern "C" int rfn_tap_scatter_f32(const float* g, float* Gs, int N, int C, int 
     return 0;
 }
 
+
+// ------------------------------------------------------------------------------------------------ per-step BatchNorm
+// The reference runs its VGG extractor / upscaler once per timestep (RFN_new.py:126-128,191-194), so every BatchNorm
+// sees the B samples of ONE step.  Time-batched here: x is [S*B, C, HW] step-major and the statistics are per (step,
+// channel) over (B, HW).  Four kernels replace the permute-copy / batch_norm / permute-copy / activation chain (and its
+// backward): statistics (two-pass, second pass from L2), apply + activation, backward reduction, backward apply.
+// act: 0 none, 1 relu, 2 leaky_relu(slope), 3 tanh.
+__device__ __forceinline__ float stepbn_act(float u, int act, float slope) {
+    if (act == 1) return u > 0.f ? u : 0.f;
+    if (act == 2) return u > 0.f ? u : slope * u;
+    if (act == 3) return tanhf(u);
+    return u;
+}
+__device__ __forceinline__ float stepbn_dact(float y, int act, float slope) {  // from the activation's OUTPUT
+    if (act == 1) return y > 0.f ? 1.f : 0.f;
+    if (act == 2) return y > 0.f ? 1.f : slope;
+    if (act == 3) return 1.f - y * y;
+    return 1.f;
+}
+// block (sc, j) = frames j, j+gridDim.y, ... of one (step, channel): shifted sums s1 = sum(x-K), s2 = sum((x-K)^2) with
+// K = the pair's first element (keeps the one-pass variance well conditioned); combined by atomics into acc[sc][2]
+__global__ __launch_bounds__(256) void stepbn_stats_kernel(const float* __restrict__ x, float* __restrict__ acc, int B,
+                                                           int C, int HW) {
+    __shared__ float sm[4];
+    const int s = blockIdx.x / C, c = blockIdx.x - s * C;
+    const float* base = x + ((long)s * B * C + c) * HW;
+    const long fs = (long)C * HW;
+    const float K = base[0];
+    float a = 0.f, v = 0.f;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const float* row = base + b * fs;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const float d = row[p] - K;
+            a += d;
+            v = fmaf(d, d, v);
+        }
+    }
+    const float ta = block_sum_256(a, sm);
+    const float tv = block_sum_256(v, sm);
+    if (threadIdx.x == 0) {
+        atomicAdd(&acc[2 * blockIdx.x], ta);
+        atomicAdd(&acc[2 * blockIdx.x + 1], tv);
+    }
+}
+__global__ void stepbn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ acc, float* __restrict__ mean,
+                                       float* __restrict__ var, int SC, int B, int C, int HW) {
+    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
+    if (sc >= SC) return;
+    const int s = sc / C, c = sc - s * C;
+    const float K = x[((long)s * B * C + c) * HW];
+    const float n = (float)B * HW;
+    const float m1 = acc[2 * sc] / n;
+    mean[sc] = K + m1;
+    const float vv = acc[2 * sc + 1] / n - m1 * m1;
+    var[sc] = vv > 0.f ? vv : 0.f;
+}
+__global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
+                                    const float* __restrict__ var, const float* __restrict__ gamma,
+                                    const float* __restrict__ beta, float* __restrict__ y, long total, int B, int C, int HW,
+                                    float eps, int act, float slope) {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / HW;          // frame * C + c
+        const int c = (int)(r % C);
+        const int s = (int)(r / C / B);
+        const int sc = s * C + c;
+        const float rstd = rsqrtf(var[sc] + eps);
+        float u = (x[idx] - mean[sc]) * rstd;
+        if (gamma) u = u * gamma[c] + beta[c];
+        y[idx] = stepbn_act(u, act, slope);
+    }
+}
+// block (sc, j): sg += sum g', sgx += sum g' * xhat over frames j, j+gridDim.y, ...  with g' = g * act'(y)
+__global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                                                const float* __restrict__ g,
+                                                                const float* __restrict__ mean,
+                                                                const float* __restrict__ var, float* __restrict__ sg,
+                                                                float* __restrict__ sgx, int B, int C, int HW, float eps,
+                                                                int act, float slope) {
+    __shared__ float sm[4];
+    const int s = blockIdx.x / C, c = blockIdx.x - s * C;
+    const long off = ((long)s * B * C + c) * HW, fs = (long)C * HW;
+    const float m = mean[blockIdx.x], rstd = rsqrtf(var[blockIdx.x] + eps);
+    float a = 0.f, ax = 0.f;
+    for (int b = blockIdx.y; b < B; b += gridDim.y) {
+        const long e0 = off + b * fs;
+        for (int p = threadIdx.x; p < HW; p += 256) {
+            const float gp = g[e0 + p] * stepbn_dact(y[e0 + p], act, slope);
+            a += gp;
+            ax = fmaf(gp, (x[e0 + p] - m) * rstd, ax);
+        }
+    }
+    const float ta = block_sum_256(a, sm);
+    const float tx = block_sum_256(ax, sm);
+    if (threadIdx.x == 0) {
+        atomicAdd(&sg[blockIdx.x], ta);
+        atomicAdd(&sgx[blockIdx.x], tx);
+    }
+}
+__global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+                                        const float* __restrict__ g, const float* __restrict__ mean,
+                                        const float* __restrict__ var, const float* __restrict__ gamma,
+                                        const float* __restrict__ sg, const float* __restrict__ sgx,
+                                        float* __restrict__ gx, long total, int B, int C, int HW, float eps, int act,
+                                        float slope) {
+    const float inv_n = 1.f / (float)(B * HW);
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        const long r = idx / HW;
+        const int c = (int)(r % C);
+        const int s = (int)(r / C / B);
+        const int sc = s * C + c;
+        const float rstd = rsqrtf(var[sc] + eps);
+        const float xh = (x[idx] - mean[sc]) * rstd;
+        const float gp = g[idx] * stepbn_dact(y[idx], act, slope);
+        const float w = gamma ? gamma[c] : 1.f;
+        gx[idx] = w * rstd * (gp - sg[sc] * inv_n - xh * sgx[sc] * inv_n);
+    }
+}
+extern "C" int rfn_stepbn_stats_f32(const float* x, float* mean, float* var, float* acc, int S, int B, int C, int HW,
+                                    rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && mean && var && acc && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    hipStream_t s = (hipStream_t)stream;
+    rfn_zero_f32(acc, 2L * S * C, s);
+    int ny = 2048 / (S * C);
+    if (ny < 1) ny = 1;
+    if (ny > B) ny = B;
+    hipLaunchKernelGGL(stepbn_stats_kernel, dim3(S * C, ny), dim3(256), 0, s, x, acc, B, C, HW);
+    hipLaunchKernelGGL(stepbn_finalize_kernel, dim3((S * C + 255) / 256), dim3(256), 0, s, x, acc, mean, var, S * C, B, C,
+                       HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int rfn_stepbn_apply_f32(const float* x, const float* mean, const float* var, const float* gamma,
+                                    const float* beta, float* y, int S, int B, int C, int HW, float eps, int act,
+                                    float slope, rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && mean && var && y && S > 0 && B > 0 && C > 0 && HW > 0 && ((gamma && beta) || (!gamma && !beta)), -1);
+    const long total = (long)S * B * C * HW;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(stepbn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta, y,
+                       total, B, C, HW, eps, act, slope);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int rfn_stepbn_bwd_reduce_f32(const float* x, const float* y, const float* g, const float* mean,
+                                         const float* var, float* sg, float* sgx, int S, int B, int C, int HW, float eps,
+                                         int act, float slope, rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && y && g && mean && var && sg && sgx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    rfn_zero_f32(sg, (long)S * C, (hipStream_t)stream);
+    rfn_zero_f32(sgx, (long)S * C, (hipStream_t)stream);
+    int ny = 2048 / (S * C);
+    if (ny < 1) ny = 1;
+    if (ny > B) ny = B;
+    hipLaunchKernelGGL(stepbn_bwd_reduce_kernel, dim3(S * C, ny), dim3(256), 0, (hipStream_t)stream, x, y, g, mean, var, sg,
+                       sgx, B, C, HW, eps, act, slope);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int rfn_stepbn_bwd_apply_f32(const float* x, const float* y, const float* g, const float* mean,
+                                        const float* var, const float* gamma, const float* sg, const float* sgx,
+                                        float* gx, int S, int B, int C, int HW, float eps, int act, float slope,
+                                        rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && y && g && mean && var && sg && sgx && gx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    const long total = (long)S * B * C * HW;
+    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
+    hipLaunchKernelGGL(stepbn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, g, mean, var, gamma,
+                       sg, sgx, gx, total, B, C, HW, eps, act, slope);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ SRNN latent step
 // RFN.loss per timestep (RFN_new.py:167-184,206-207): enc / pri are the outputs [B, 2*Z, HW] of the encoder / prior
 // parameter convs (loc | raw scale, "chunk(2,1)" halves, SimpleParamNet.forward Utils/modules.py:240-244):

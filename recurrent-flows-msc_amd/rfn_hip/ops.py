@@ -842,3 +842,44 @@ class ConvLSTMSeqFn(torch.autograd.Function):
         gw = conv2d_wgrad(x_all.view(S * B, Cx, H, W), h_prev_all, G, 4 * Hc, 3)
         gb = G.sum(dim=(0, 2, 3)) if ctx.has_bias else None
         return gx_all, gh_rec, gc, gw, gb
+
+
+class StepBatchNormActFn(torch.autograd.Function):
+    """Training-mode BatchNorm2d with per-timestep statistics on a step-major time-batched tensor [S*B, C, H, W],
+    fused with the activation that follows it (rfn_stepbn_*_f32).  Returns (y, mean[S, C], biased var[S, C]); the
+    caller applies the running-statistics EMA.  act: 0 none, 1 relu, 2 leaky_relu(slope), 3 tanh."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, S, eps, act, slope):
+        x = x.contiguous()
+        SB, C, H, W = (int(v) for v in x.shape)
+        B, HW = SB // S, H * W
+        mean = torch.empty((S, C), device=x.device, dtype=torch.float32)
+        var = torch.empty((S, C), device=x.device, dtype=torch.float32)
+        y = torch.empty_like(x)
+        gm = None if gamma is None else gamma.detach().contiguous()
+        bt = None if beta is None else beta.detach().contiguous()
+        acc = torch.empty((S, C, 2), device=x.device, dtype=torch.float32)  # scratch of the split reduction
+        L.call("rfn_stepbn_stats_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(acc), _i(S), _i(B), _i(C), _i(HW))
+        L.call("rfn_stepbn_apply_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(gm), L.dev(bt), L.dev(y), _i(S), _i(B),
+               _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
+        ctx.save_for_backward(x, y, mean, var, gm)
+        ctx.cfg = (S, B, C, HW, eps, act, slope, gamma is not None)
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
+    def backward(ctx, g, _gm, _gv):
+        x, y, mean, var, gm = ctx.saved_tensors
+        S, B, C, HW, eps, act, slope, affine = ctx.cfg
+        g = g.contiguous()
+        sg = torch.empty((S, C), device=x.device, dtype=torch.float32)
+        sgx = torch.empty((S, C), device=x.device, dtype=torch.float32)
+        gx = torch.empty_like(x)
+        L.call("rfn_stepbn_bwd_reduce_f32", L.dev(x), L.dev(y), L.dev(g), L.dev(mean), L.dev(var), L.dev(sg), L.dev(sgx),
+               _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
+        L.call("rfn_stepbn_bwd_apply_f32", L.dev(x), L.dev(y), L.dev(g), L.dev(mean), L.dev(var), L.dev(gm), L.dev(sg),
+               L.dev(sgx), L.dev(gx), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
+        ggamma = sgx.sum(0) if affine else None
+        gbeta = sg.sum(0) if affine else None
+        return gx, ggamma, gbeta, None, None, None, None

@@ -312,6 +312,44 @@ def test_convlstm_sequence_node_equals_per_step_cells(B, Cx, Hc, H, W, S, conv_p
         assert err < 5e-5, (name, err)
 
 
+@pytest.mark.parametrize("S,B,C,H,W,act", [(3, 4, 6, 8, 8, "leakyrelu"), (5, 2, 16, 2, 2, "relu"), (2, 3, 5, 4, 6, "tanh"),
+                                           (4, 3, 8, 1, 2, None)])
+def test_fused_per_step_batchnorm_activation(S, B, C, H, W, act):
+    """rfn_stepbn_* through run_time_batched: BatchNorm2d (training) with the statistics of each timestep's B samples,
+    fused with the following activation, against S separate calls of the torch modules (what the reference's
+    per-frame extractor / upscaler calls do, RFN_new.py:126-128): output, input / affine gradients, running statistics."""
+    import copy
+    import torch.nn as nn
+    from Utils.modules import NormLayer, ActFun, run_time_batched
+    torch.manual_seed(21)
+    layers = [NormLayer(C, "batchnorm")]
+    if act in ("relu", "leakyrelu"):
+        layers.append(ActFun(act))
+    elif act == "tanh":
+        layers.append(nn.Tanh())
+    seq = nn.Sequential(*layers).cuda().train()
+    with torch.no_grad():
+        seq[0].norm.weight.uniform_(0.5, 1.5)
+        seq[0].norm.bias.uniform_(-0.5, 0.5)
+    ref = copy.deepcopy(seq)
+    g = torch.Generator().manual_seed(22)
+    x = (torch.randn(S * B, C, H, W, generator=g) * 2 + 0.7).cuda()
+    gy = torch.randn(S * B, C, H, W, generator=g).cuda()
+    xa, xb = x.clone().requires_grad_(True), x.clone().requires_grad_(True)
+    ya = run_time_batched(seq, xa, S)
+    yb = torch.cat([ref(xb[t * B:(t + 1) * B]) for t in range(S)], 0)
+    (ya * gy).sum().backward()
+    (yb * gy).sum().backward()
+    rel = lambda u, v: float((u - v).abs().max() / (v.abs().max() + 1e-12))
+    assert rel(ya, yb) < 2e-5
+    assert rel(xa.grad, xb.grad) < 1e-4
+    assert rel(seq[0].norm.weight.grad, ref[0].norm.weight.grad) < 1e-4
+    assert rel(seq[0].norm.bias.grad, ref[0].norm.bias.grad) < 1e-4
+    assert rel(seq[0].norm.running_mean, ref[0].norm.running_mean) < 1e-5
+    assert rel(seq[0].norm.running_var, ref[0].norm.running_var) < 1e-5
+    assert int(seq[0].norm.num_batches_tracked) == int(ref[0].norm.num_batches_tracked)
+
+
 def test_graph_captured_step_equals_eager_step():
     """Solver in hipGraph mode (fwd+bwd captured, replayed) produces the same loss and gradients as the eager step."""
     import __graft_entry__ as ge
