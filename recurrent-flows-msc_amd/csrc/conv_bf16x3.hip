@@ -413,7 +413,10 @@ static int dispatch_conv_b3(ConvParams& p, int ks, hipStream_t s);
 static bool conv1x1_ws_eligible(int ks, int Cin, int C2, int Cout, long npix);
 static bool conv3x3_ws_rows(int N, int H, int W, int ks, int Cout, int Cin, int* rows);
 extern "C" int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout, int Cin) {
-    if (conv1x1_ws_eligible(ks, Cin, 0, Cout, (long)N * H * W)) return (int)(((long)N * H * W + 31) / 32);
+    if (conv1x1_ws_eligible(ks, Cin, 0, Cout, (long)N * H * W)) {
+        const long nt = ((long)N * H * W + 31) / 32;
+        return (int)(nt < 256 ? nt : 256);  // one row per persistent workgroup
+    }
     int ws3_rows = 0;
     if (conv3x3_ws_rows(N, H, W, ks, Cout, Cin, &ws3_rows)) return ws3_rows;
     ConvParams p;
@@ -496,6 +499,8 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p, con
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     bf16x8* Bs = reinterpret_cast<bf16x8*>(lds_raw);                       // [2 buffers][plane][NG][TP]
     float* ep = reinterpret_cast<float*>(Bs + 2 * 2 * NG * TP);            // [2][256]
+    float* psum = ep + 2 * 256;                                            // [256][2] running sums of ep_mode 4
+    for (int c = threadIdx.x; c < 512; c += 512) psum[c] = 0.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
@@ -608,7 +613,12 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p, con
         const long q = (long)tile * TP + l31;
         pvalid[0] = q < total;
         split_q(pvalid[0] ? q : 0, pn[0], ppix[0]);
-        conv_epilogue<1, 1, 256>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile);
+        conv_epilogue<1, 1, 256>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile, psum);
+    }
+    if (p.ep_mode == 4) {  // one row of partial sums per workgroup
+        __syncthreads();
+        for (int c = tid; c < 512; c += 512)
+            p.part[((long)blockIdx.x * p.Cout + blockIdx.y * 256) * 2 + c] = psum[c];
     }
 }
 
@@ -630,6 +640,8 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
     const int IMGP = (IMG + 3) & ~3;
     bf16x8* Bs = reinterpret_cast<bf16x8*>(lds_raw);                        // [2 buffers][plane][NG][IMGP]
     float* ep = reinterpret_cast<float*>(Bs + 2 * 2 * NG * IMGP);           // [2][256]
+    float* psum = ep + 2 * 256;                                             // [256][2] running sums of ep_mode 4
+    for (int c = threadIdx.x; c < 512; c += 512) psum[c] = 0.f;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
@@ -759,7 +771,12 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
             ppix[t] = (y0 + prow[t]) * p.W + x0 + pcol[t];
             pvalid[t] = true;
         }
-        conv_epilogue<1, PT, 256, FASTEP>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile);
+        conv_epilogue<1, PT, 256, FASTEP>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile, psum);
+    }
+    if (!FASTEP && p.ep_mode == 4) {  // one row of partial sums per workgroup
+        __syncthreads();
+        for (int c = tid; c < 512; c += 512)
+            p.part[((long)blockIdx.x * p.Cout + blockIdx.y * 256) * 2 + c] = psum[c];
     }
 }
 
@@ -778,7 +795,8 @@ static bool conv3x3_ws_rows(int N, int H, int W, int ks, int Cout, int Cin, int*
     memset(&p, 0, sizeof(p));
     p.N = N; p.H = H; p.W = W; p.Cout = Cout; p.cout_split = Cout; p.C1 = Cin; p.ep_mode = 4;
     if (!conv3x3_ws_eligible(p, ks)) return false;
-    *rows = (int)((long)N * H * W / 64);
+    const long nt = (long)N * H * W / 64;
+    *rows = (int)(nt < 256 ? nt : 256);  // one row per persistent workgroup
     return true;
 }
 
@@ -795,7 +813,7 @@ static int launch_conv3x3_ws_t(ConvParams& p, hipStream_t s) {
         return -8;
     }
     p.ksplit = 1;
-    const size_t lds = (size_t)2 * 2 * NG * IMGP * 16 + 2 * 256 * 4;
+    const size_t lds = (size_t)2 * 2 * NG * IMGP * 16 + 4 * 256 * 4;
     auto kern = conv3x3_ws_kernel<NG, PT, FASTEP>;
     dim3 grid(n_tiles < 256 ? n_tiles : 256, p.Cout / 256);
     hipLaunchKernelGGL(kern, grid, dim3(512), lds, s, p, n_tiles, tw_shift, tpf_shift, wt_shift);
@@ -819,7 +837,7 @@ static int launch_conv1x1_ws(ConvParams& p, hipStream_t s) {
     int hw_shift = -1;
     if ((HW & (HW - 1)) == 0) hw_shift = ilog2(HW);
     p.ksplit = 1;
-    const size_t lds = (size_t)2 * 2 * 32 * 32 * 16 + 2 * 256 * 4;
+    const size_t lds = (size_t)2 * 2 * 32 * 32 * 16 + 4 * 256 * 4;
     auto kern = conv1x1_ws_kernel<16>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(n_tiles < 256 ? n_tiles : 256, p.Cout / 256);

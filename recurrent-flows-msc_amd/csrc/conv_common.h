@@ -56,7 +56,8 @@ template <int TCO, int TPX, int BCO, bool FASTONLY = false>
 __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)[TCO][TPX], const float* ep,
                                               const int co_base, const int wco, const int kk, const int HW,
                                               const int (&pn)[TPX], const int (&ppix)[TPX],
-                                              const bool (&pvalid)[TPX], const int prow = 0) {
+                                              const bool (&pvalid)[TPX], const int prow = 0,
+                                              float* const lds_part = nullptr) {
     const int cl_base = wco * (32 * TCO) + 4 * kk;  // channel index inside the block for (a=0, r=0)
     const bool fast = FASTONLY || ((co_base + 32 * TCO <= p.Cout) && (p.cout_split == p.Cout));  // wave-uniform
     if (!FASTONLY && p.ep_mode == 4) {
@@ -103,9 +104,17 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 sb = half_wave_sum_dpp(sb);  // lanes of one 32-lane half share the channel
                 sl = half_wave_sum_dpp(sl);
                 if (l31 == 16) {
-                    float* dst = p.part + ((long)prow * p.Cout + co_base + cidx + 4 * kk) * 2;
-                    dst[0] = sb;
-                    dst[1] = sl;
+                    if (lds_part) {
+                        // persistent kernels: running sums of the workgroup in LDS [BCO][2] (this lane is the only
+                        // owner of its channel), flushed once per workgroup instead of one row per pixel tile
+                        float* dst = lds_part + (cl_base + cidx) * 2;
+                        dst[0] += sb;
+                        dst[1] += sl;
+                    } else {
+                        float* dst = p.part + ((long)prow * p.Cout + co_base + cidx + 4 * kk) * 2;
+                        dst[0] = sb;
+                        dst[1] = sl;
+                    }
                 }
             }
         }
