@@ -111,6 +111,16 @@ def kernel_roofline(rec, steps):
             "all_mfma_kernels": {"achieved_TFLOPs_fp32_equiv": mfma_fl / (mfma_ms * 1e-3) / 1e12,
                                  "ms_per_step": mfma_ms / steps, "flops_per_step": mfma_fl / steps},
             "hip_kernel_ms_per_step": tot_ms / steps}
+    # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same workload (FETCH_SIZE /
+    # WRITE_SIZE cannot be read from inside the process); the committed summary is attached when it is for this kernel
+    try:
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_dominant_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("kernel") and pmc["kernel"] in dom:
+            roof["traffic"] = pmc["traffic_bytes_per_launch"]
+            roof["traffic_source"] = "profiles/r01_pmc_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes)"
+    except (OSError, ValueError):
+        pass
     table = sorted(([k, v["calls"] // steps, round(v["ms"] / steps, 3),
                      round(v["flops"] / max(v["ms"], 1e-9) / 1e9, 2), round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)]
                     for k, v in groups.items()), key=lambda r: -r[2])

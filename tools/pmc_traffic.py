@@ -1,0 +1,17 @@
+"""Developer tool: mean HBM bytes per launch of one kernel symbol from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE)
+of the bench child.  usage: pmc_traffic.py <fetch_dir> <write_dir> <symbol substring> <out.json>
+gfx950 corrections (MI355X_MICROARCH.md, HBM): counters are in KB; FETCH_SIZE tallies 128-B requests at 64 B -> x2."""
+import csv, glob, json, sys
+def mean_kb(d, counter, sym):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
+            if r["Counter_Name"] == counter and sym in r["Kernel_Name"]]
+    return sum(vals) / len(vals), len(vals)
+fetch, n1 = mean_kb(sys.argv[1], "FETCH_SIZE", sys.argv[3])
+write, n2 = mean_kb(sys.argv[2], "WRITE_SIZE", sys.argv[3])
+out = {"kernel": sys.argv[3], "dispatches": [n1, n2], "fetch_bytes_per_launch": 2.0 * fetch * 1024,
+       "write_bytes_per_launch": write * 1024, "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024,
+       "corrections": "KB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B)",
+       "command": "rocprofv3 --pmc <counter> -- python3 bench.py --child --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-roofline"}
+json.dump(out, open(sys.argv[4], "w"), indent=1)
+print(json.dumps(out))
