@@ -225,16 +225,16 @@ int rfn_smallmap_conv_bf16x3(const float* in1, long in1_ns, int C1, const float*
 /* ---- callers of the path (VGG extractor / upscaler, Utils/modules.py:43-213): BatchNorm2d (training mode) + the
  * activation that follows it on a step-major time-batched tensor x [S*B, C, HW] with the statistics of EACH step's B
  * samples, as the reference's per-timestep calls compute them (RFN_new.py:126-128,191-194).  mean / var (biased) are
- * [S*C]; act: 0 none, 1 relu, 2 leaky_relu(slope), 3 tanh; gamma / beta may both be NULL.  Backward: g' = g*act'(y),
+ * [S*C]; act: 0 none, 1 relu, 2 leaky_relu(slope), 3 tanh; gamma / beta may both be NULL.  Backward: g' = g*act'(u) with u = xhat*gamma + beta recomputed from x (the output is not read),
  * sg = sum g', sgx = sum g'*xhat per (step, channel), gx = gamma*rstd*(g' - sg/n - xhat*sgx/n). */
 int rfn_stepbn_stats_f32(const float* x, float* mean, float* var, float* acc /* scratch [2*S*C] */, int S, int B, int C,
                          int HW, rfn_stream_t stream);
 int rfn_stepbn_apply_f32(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
                          float* y, int S, int B, int C, int HW, float eps, int act, float slope, rfn_stream_t stream);
-int rfn_stepbn_bwd_reduce_f32(const float* x, const float* y, const float* g, const float* mean, const float* var,
-                              float* sg, float* sgx, int S, int B, int C, int HW, float eps, int act, float slope,
-                              rfn_stream_t stream);
-int rfn_stepbn_bwd_apply_f32(const float* x, const float* y, const float* g, const float* mean, const float* var,
+int rfn_stepbn_bwd_reduce_f32(const float* x, const float* gamma, const float* beta, const float* g, const float* mean,
+                              const float* var, float* sg, float* sgx, int S, int B, int C, int HW, float eps, int act,
+                              float slope, rfn_stream_t stream);
+int rfn_stepbn_bwd_apply_f32(const float* x, const float* beta, const float* g, const float* mean, const float* var,
                              const float* gamma, const float* sg, const float* sgx, float* gx, int S, int B, int C,
                              int HW, float eps, int act, float slope, rfn_stream_t stream);
 

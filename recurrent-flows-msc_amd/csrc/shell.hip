@@ -846,10 +846,13 @@ __device__ __forceinline__ float stepbn_act(float u, int act, float slope) {
     if (act == 3) return tanhf(u);
     return u;
 }
-__device__ __forceinline__ float stepbn_dact(float y, int act, float slope) {  // from the activation's OUTPUT
-    if (act == 1) return y > 0.f ? 1.f : 0.f;
-    if (act == 2) return y > 0.f ? 1.f : slope;
-    if (act == 3) return 1.f - y * y;
+__device__ __forceinline__ float stepbn_dact(float u, int act, float slope) {  // from the activation's INPUT u = xhat*g + b
+    if (act == 1) return u > 0.f ? 1.f : 0.f;                                  // (recomputed: saves a pass over y)
+    if (act == 2) return u > 0.f ? 1.f : slope;
+    if (act == 3) {
+        const float t = tanhf(u);
+        return 1.f - t * t;
+    }
     return 1.f;
 }
 // block (sc, j) = frames j, j+gridDim.y, ... of one (step, channel): shifted sums s1 = sum(x-K), s2 = sum((x-K)^2) with
@@ -905,7 +908,9 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
     }
 }
 // block (sc, j): sg += sum g', sgx += sum g' * xhat over frames j, j+gridDim.y, ...  with g' = g * act'(y)
-__global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __restrict__ x,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta,
                                                                 const float* __restrict__ g,
                                                                 const float* __restrict__ mean,
                                                                 const float* __restrict__ var, float* __restrict__ sg,
@@ -915,13 +920,15 @@ __global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __r
     const int s = blockIdx.x / C, c = blockIdx.x - s * C;
     const long off = ((long)s * B * C + c) * HW, fs = (long)C * HW;
     const float m = mean[blockIdx.x], rstd = rsqrtf(var[blockIdx.x] + eps);
+    const float ga = gamma ? gamma[c] : 1.f, be = gamma ? beta[c] : 0.f;
     float a = 0.f, ax = 0.f;
     for (int b = blockIdx.y; b < B; b += gridDim.y) {
         const long e0 = off + b * fs;
         for (int p = threadIdx.x; p < HW; p += 256) {
-            const float gp = g[e0 + p] * stepbn_dact(y[e0 + p], act, slope);
+            const float xh = (x[e0 + p] - m) * rstd;
+            const float gp = g[e0 + p] * stepbn_dact(xh * ga + be, act, slope);
             a += gp;
-            ax = fmaf(gp, (x[e0 + p] - m) * rstd, ax);
+            ax = fmaf(gp, xh, ax);
         }
     }
     const float ta = block_sum_256(a, sm);
@@ -931,7 +938,7 @@ __global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __r
         atomicAdd(&sgx[blockIdx.x], tx);
     }
 }
-__global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ y,
+__global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ beta,
                                         const float* __restrict__ g, const float* __restrict__ mean,
                                         const float* __restrict__ var, const float* __restrict__ gamma,
                                         const float* __restrict__ sg, const float* __restrict__ sgx,
@@ -945,8 +952,8 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
         const int sc = s * C + c;
         const float rstd = rsqrtf(var[sc] + eps);
         const float xh = (x[idx] - mean[sc]) * rstd;
-        const float gp = g[idx] * stepbn_dact(y[idx], act, slope);
         const float w = gamma ? gamma[c] : 1.f;
+        const float gp = g[idx] * stepbn_dact(xh * w + (gamma ? beta[c] : 0.f), act, slope);
         gx[idx] = w * rstd * (gp - sg[sc] * inv_n - xh * sgx[sc] * inv_n);
     }
 }
@@ -975,28 +982,30 @@ extern "C" int rfn_stepbn_apply_f32(const float* x, const float* mean, const flo
     RFN_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int rfn_stepbn_bwd_reduce_f32(const float* x, const float* y, const float* g, const float* mean,
-                                         const float* var, float* sg, float* sgx, int S, int B, int C, int HW, float eps,
-                                         int act, float slope, rfn_stream_t stream) {
-    RFN_CHECK_ARG(x && y && g && mean && var && sg && sgx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+extern "C" int rfn_stepbn_bwd_reduce_f32(const float* x, const float* gamma, const float* beta, const float* g,
+                                         const float* mean, const float* var, float* sg, float* sgx, int S, int B, int C,
+                                         int HW, float eps, int act, float slope, rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && g && mean && var && sg && sgx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    RFN_CHECK_ARG((gamma && beta) || (!gamma && !beta), -2);
     rfn_zero_f32(sg, (long)S * C, (hipStream_t)stream);
     rfn_zero_f32(sgx, (long)S * C, (hipStream_t)stream);
     int ny = 2048 / (S * C);
     if (ny < 1) ny = 1;
     if (ny > B) ny = B;
-    hipLaunchKernelGGL(stepbn_bwd_reduce_kernel, dim3(S * C, ny), dim3(256), 0, (hipStream_t)stream, x, y, g, mean, var, sg,
-                       sgx, B, C, HW, eps, act, slope);
+    hipLaunchKernelGGL(stepbn_bwd_reduce_kernel, dim3(S * C, ny), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, g, mean,
+                       var, sg, sgx, B, C, HW, eps, act, slope);
     RFN_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int rfn_stepbn_bwd_apply_f32(const float* x, const float* y, const float* g, const float* mean,
+extern "C" int rfn_stepbn_bwd_apply_f32(const float* x, const float* beta, const float* g, const float* mean,
                                         const float* var, const float* gamma, const float* sg, const float* sgx,
                                         float* gx, int S, int B, int C, int HW, float eps, int act, float slope,
                                         rfn_stream_t stream) {
-    RFN_CHECK_ARG(x && y && g && mean && var && sg && sgx && gx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    RFN_CHECK_ARG(x && g && mean && var && sg && sgx && gx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    RFN_CHECK_ARG((gamma && beta) || (!gamma && !beta), -2);
     const long total = (long)S * B * C * HW;
     const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(stepbn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, y, g, mean, var, gamma,
+    hipLaunchKernelGGL(stepbn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, g, mean, var, gamma,
                        sg, sgx, gx, total, B, C, HW, eps, act, slope);
     RFN_LAUNCH_CHECK();
     return 0;

@@ -67,8 +67,8 @@ SIGNATURES = {
     "rfn_stepbn_stats_f32": [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_stepbn_apply_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float, _c_i,
                              ctypes.c_float, _c_s],
-    "rfn_stepbn_bwd_reduce_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float, _c_i,
-                                  ctypes.c_float, _c_s],
+    "rfn_stepbn_bwd_reduce_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float,
+                                  _c_i, ctypes.c_float, _c_s],
     "rfn_stepbn_bwd_apply_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i,
                                  ctypes.c_float, _c_i, ctypes.c_float, _c_s],
     "rfn_convlstm_gates_fwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,

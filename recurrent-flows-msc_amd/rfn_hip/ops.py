@@ -863,22 +863,22 @@ class StepBatchNormActFn(torch.autograd.Function):
         L.call("rfn_stepbn_stats_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(acc), _i(S), _i(B), _i(C), _i(HW))
         L.call("rfn_stepbn_apply_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(gm), L.dev(bt), L.dev(y), _i(S), _i(B),
                _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
-        ctx.save_for_backward(x, y, mean, var, gm)
+        ctx.save_for_backward(x, mean, var, gm, bt)
         ctx.cfg = (S, B, C, HW, eps, act, slope, gamma is not None)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
-        x, y, mean, var, gm = ctx.saved_tensors
+        x, mean, var, gm, bt = ctx.saved_tensors
         S, B, C, HW, eps, act, slope, affine = ctx.cfg
         g = g.contiguous()
         sg = torch.empty((S, C), device=x.device, dtype=torch.float32)
         sgx = torch.empty((S, C), device=x.device, dtype=torch.float32)
         gx = torch.empty_like(x)
-        L.call("rfn_stepbn_bwd_reduce_f32", L.dev(x), L.dev(y), L.dev(g), L.dev(mean), L.dev(var), L.dev(sg), L.dev(sgx),
-               _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
-        L.call("rfn_stepbn_bwd_apply_f32", L.dev(x), L.dev(y), L.dev(g), L.dev(mean), L.dev(var), L.dev(gm), L.dev(sg),
+        L.call("rfn_stepbn_bwd_reduce_f32", L.dev(x), L.dev(gm), L.dev(bt), L.dev(g), L.dev(mean), L.dev(var), L.dev(sg),
+               L.dev(sgx), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
+        L.call("rfn_stepbn_bwd_apply_f32", L.dev(x), L.dev(bt), L.dev(g), L.dev(mean), L.dev(var), L.dev(gm), L.dev(sg),
                L.dev(sgx), L.dev(gx), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
         ggamma = sgx.sum(0) if affine else None
         gbeta = sg.sum(0) if affine else None
