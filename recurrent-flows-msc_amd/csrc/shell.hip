@@ -892,19 +892,35 @@ __global__ void stepbn_finalize_kernel(const float* __restrict__ x, const float*
     const float vv = acc[2 * sc + 1] / n - m1 * m1;
     var[sc] = vv > 0.f ? vv : 0.f;
 }
+// elementwise kernels: VEC = 4 consecutive pixels per thread when HW % 4 == 0 (16-byte accesses); 32-bit index math
+// (the host checks total < 2^31)
+template <int VEC>
 __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ var, const float* __restrict__ gamma,
-                                    const float* __restrict__ beta, float* __restrict__ y, long total, int B, int C, int HW,
-                                    float eps, int act, float slope) {
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long r = idx / HW;          // frame * C + c
-        const int c = (int)(r % C);
-        const int s = (int)(r / C / B);
+                                    const float* __restrict__ beta, float* __restrict__ y, unsigned total, int B, int C,
+                                    int HW, float eps, int act, float slope) {
+    const unsigned nvec = total / VEC;
+    for (unsigned iv = blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += gridDim.x * blockDim.x) {
+        const unsigned idx = iv * VEC;
+        const unsigned r = idx / (unsigned)HW;  // frame * C + c
+        const int c = (int)(r % (unsigned)C);
+        const int s = (int)(r / (unsigned)C / (unsigned)B);
         const int sc = s * C + c;
-        const float rstd = rsqrtf(var[sc] + eps);
-        float u = (x[idx] - mean[sc]) * rstd;
-        if (gamma) u = u * gamma[c] + beta[c];
-        y[idx] = stepbn_act(u, act, slope);
+        const float rstd = rsqrtf(var[sc] + eps), m = mean[sc];
+        const float ga = gamma ? gamma[c] : 1.f, be = gamma ? beta[c] : 0.f;
+        float v[VEC];
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(x + idx);
+            v[0] = t.x; v[1 % VEC] = t.y; v[2 % VEC] = t.z; v[3 % VEC] = t.w;
+        } else {
+            v[0] = x[idx];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) v[j] = stepbn_act((v[j] - m) * rstd * ga + be, act, slope);
+        if (VEC == 4)
+            *reinterpret_cast<float4*>(y + idx) = float4{v[0], v[1 % VEC], v[2 % VEC], v[3 % VEC]};
+        else
+            y[idx] = v[0];
     }
 }
 // block (sc, j): sg += sum g', sgx += sum g' * xhat over frames j, j+gridDim.y, ...  with g' = g * act'(y)
@@ -938,23 +954,44 @@ __global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __r
         atomicAdd(&sgx[blockIdx.x], tx);
     }
 }
+template <int VEC>
 __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ beta,
                                         const float* __restrict__ g, const float* __restrict__ mean,
                                         const float* __restrict__ var, const float* __restrict__ gamma,
                                         const float* __restrict__ sg, const float* __restrict__ sgx,
-                                        float* __restrict__ gx, long total, int B, int C, int HW, float eps, int act,
+                                        float* __restrict__ gx, unsigned total, int B, int C, int HW, float eps, int act,
                                         float slope) {
     const float inv_n = 1.f / (float)(B * HW);
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const long r = idx / HW;
-        const int c = (int)(r % C);
-        const int s = (int)(r / C / B);
+    const unsigned nvec = total / VEC;
+    for (unsigned iv = blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += gridDim.x * blockDim.x) {
+        const unsigned idx = iv * VEC;
+        const unsigned r = idx / (unsigned)HW;
+        const int c = (int)(r % (unsigned)C);
+        const int s = (int)(r / (unsigned)C / (unsigned)B);
         const int sc = s * C + c;
-        const float rstd = rsqrtf(var[sc] + eps);
-        const float xh = (x[idx] - mean[sc]) * rstd;
-        const float w = gamma ? gamma[c] : 1.f;
-        const float gp = g[idx] * stepbn_dact(xh * w + (gamma ? beta[c] : 0.f), act, slope);
-        gx[idx] = w * rstd * (gp - sg[sc] * inv_n - xh * sgx[sc] * inv_n);
+        const float rstd = rsqrtf(var[sc] + eps), m = mean[sc];
+        const float w = gamma ? gamma[c] : 1.f, be = gamma ? beta[c] : 0.f;
+        const float k1 = sg[sc] * inv_n, k2 = sgx[sc] * inv_n;
+        float xv[VEC], gv[VEC];
+        if (VEC == 4) {
+            const float4 t = *reinterpret_cast<const float4*>(x + idx);
+            const float4 u = *reinterpret_cast<const float4*>(g + idx);
+            xv[0] = t.x; xv[1 % VEC] = t.y; xv[2 % VEC] = t.z; xv[3 % VEC] = t.w;
+            gv[0] = u.x; gv[1 % VEC] = u.y; gv[2 % VEC] = u.z; gv[3 % VEC] = u.w;
+        } else {
+            xv[0] = x[idx];
+            gv[0] = g[idx];
+        }
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) {
+            const float xh = (xv[j] - m) * rstd;
+            const float gp = gv[j] * stepbn_dact(xh * w + be, act, slope);
+            xv[j] = w * rstd * (gp - k1 - xh * k2);
+        }
+        if (VEC == 4)
+            *reinterpret_cast<float4*>(gx + idx) = float4{xv[0], xv[1 % VEC], xv[2 % VEC], xv[3 % VEC]};
+        else
+            gx[idx] = xv[0];
     }
 }
 extern "C" int rfn_stepbn_stats_f32(const float* x, float* mean, float* var, float* acc, int S, int B, int C, int HW,
@@ -976,9 +1013,16 @@ extern "C" int rfn_stepbn_apply_f32(const float* x, const float* mean, const flo
                                     float slope, rfn_stream_t stream) {
     RFN_CHECK_ARG(x && mean && var && y && S > 0 && B > 0 && C > 0 && HW > 0 && ((gamma && beta) || (!gamma && !beta)), -1);
     const long total = (long)S * B * C * HW;
-    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(stepbn_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta, y,
-                       total, B, C, HW, eps, act, slope);
+    RFN_CHECK_ARG(total < (1L << 31), -2);
+    const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    const long nthr = v4 ? total / 4 : total;
+    const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
+    if (v4)
+        hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta,
+                           y, (unsigned)total, B, C, HW, eps, act, slope);
+    else
+        hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta,
+                           y, (unsigned)total, B, C, HW, eps, act, slope);
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -1004,9 +1048,16 @@ extern "C" int rfn_stepbn_bwd_apply_f32(const float* x, const float* beta, const
     RFN_CHECK_ARG(x && g && mean && var && sg && sgx && gx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
     RFN_CHECK_ARG((gamma && beta) || (!gamma && !beta), -2);
     const long total = (long)S * B * C * HW;
-    const int grid = (int)((total + 255) / 256 < 16384 ? (total + 255) / 256 : 16384);
-    hipLaunchKernelGGL(stepbn_bwd_apply_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, g, mean, var, gamma,
-                       sg, sgx, gx, total, B, C, HW, eps, act, slope);
+    RFN_CHECK_ARG(total < (1L << 31), -3);
+    const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx) & 15) == 0;
+    const long nthr = v4 ? total / 4 : total;
+    const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
+    if (v4)
+        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, g, mean, var,
+                           gamma, sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope);
+    else
+        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, g, mean, var,
+                           gamma, sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope);
     RFN_LAUNCH_CHECK();
     return 0;
 }
