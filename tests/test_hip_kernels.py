@@ -116,6 +116,8 @@ CONV_CASES = [
     (70, 4, 14, 256, 16, 16, 3),    # same kernel, 2 x 16 pixel tiles
     (300, 10, 0, 256, 8, 8, 3),     # same kernel, 4 x 8 pixel tiles, single source, Cin not a multiple of 8
     (70, 4, 32, 256, 16, 16, 3),    # same kernel, 45-unit variant (24 < Cin <= 40): level-1 conv1
+    (70, 6, 12, 512, 16, 16, 3),    # weight-stationary 3x3 with two 256-channel output blocks (Hd = 512)
+    (70, 200, 0, 512, 16, 16, 1),   # weight-stationary 1x1 with two output blocks
 ]
 
 
@@ -143,6 +145,30 @@ def test_conv2d_fwd_dgrad_wgrad(K, case):
         assert relerr(g2, xin.grad[:, C1:]) < 2e-5 * ctol(), "dgrad in2"
     gw = K.conv2d_wgrad(cu(x1), cu(x2) if C2 else None, cu(gy), Cout, ks)
     assert relerr(gw, wr.grad) < 1e-4, "wgrad"  # both arithmetics
+
+
+@pytest.mark.parametrize("N,Cmid,Cnext,S,ks,act", [(70, 256, 8, 16, 3, 2), (70, 256, 256, 16, 1, 2), (66, 512, 4, 16, 3, 1),
+                                                   (3, 64, 6, 8, 3, 2), (5, 128, 64, 4, 1, 1)])
+def test_dgrad_with_fused_activation_backward(K, N, Cmid, Cnext, S, ks, act):
+    """rfn_conv2d_dgrad_act_bf16x3: data gradient of a conv fused with the backward of the producer's ActNorm +
+    activation (gu, grad bias, grad logs) against autograd of  y = act((u + b) * exp(l)),  o = conv(y, w).  The first
+    three cases have >= 16384 pixels and take the weight-stationary kernels (per-workgroup partial sums)."""
+    if K.CONV_PRECISION != "bf16x3":
+        pytest.skip("fused epilogue exists in the split-precision kernels only")
+    g = torch.Generator().manual_seed(33)
+    u = torch.randn(N, Cmid, S, S, generator=g).requires_grad_(True)
+    b = (torch.randn(Cmid, generator=g) * 0.3).requires_grad_(True)
+    l = (torch.randn(Cmid, generator=g) * 0.2).requires_grad_(True)
+    w = torch.randn(Cnext, Cmid, ks, ks, generator=g) / (Cmid * ks * ks) ** 0.5
+    pre = (u + b.view(1, -1, 1, 1)) * l.view(1, -1, 1, 1).exp()
+    y = F.relu(pre) if act == 1 else F.leaky_relu(pre, 0.2)
+    o = F.conv2d(y, w, None, padding=ks // 2)
+    go = torch.randn(o.shape, generator=g)
+    o.backward(go)
+    gu, gb, gl = K.conv2d_dgrad_act(cu(go), K.pack_weight(cu(w), True), cu(y.detach()), cu(l.detach()), act, Cmid, ks)
+    assert relerr(gu, u.grad) < 3e-5
+    assert relerr(gb, b.grad) < 1e-4
+    assert relerr(gl, l.grad) < 1e-4
 
 
 @pytest.mark.parametrize("ep_mode,act", [(1, 1), (1, 2), (1, 0), (2, 0), (3, 0)])

@@ -442,41 +442,56 @@ def test_graph_replays_are_reproducible_canonical_architecture():
                                            msg=lambda m: "replay %d %s: %s" % (r, n, m))
 
 
-def test_glowstep_hd64_gradients_vs_oracle(conv_precision):
-    """hidden width 64 takes the fused data-gradient + activation-backward kernels (the golden fixtures use 16)."""
+@pytest.mark.parametrize("Hd,N,C,Cc,S", [(64, 3, 8, 6, 8), (256, 70, 8, 12, 16), (512, 66, 4, 10, 16)])
+def test_glowstep_hd64_gradients_vs_oracle(conv_precision, Hd, N, C, Cc, S):
+    """hidden width 64 takes the fused data-gradient + activation-backward kernels (the golden fixtures use 16); the
+    256 / 512 wide cases have enough pixels (>= 16384) for the weight-stationary 1x1 / 3x3 kernels, the implicit 3x3
+    weight gradient and (512) two 256-channel output blocks."""
     from Flow import GlowStep
     from tests.golden_args import GLOW_DEFAULTS
     a = dict(GLOW_DEFAULTS)
-    a["n_units_affine"] = 64
+    a["n_units_affine"] = Hd
     torch.manual_seed(12)
-    gs = GlowStep([3, 8, 8, 8], [3, 6, 8, 8], glow_ns(a)).cuda().train()
+    gs = GlowStep([N, C, S, S], [N, Cc, S, S], glow_ns(a)).cuda().train()
     g = torch.Generator().manual_seed(13)
-    x0 = torch.randn(3, 8, 8, 8, generator=g)
-    c0 = torch.randn(3, 6, 8, 8, generator=g)
-    gs(cu(x0), cu(c0), torch.zeros(3, device="cuda"), False)  # data dependent init
+    x0 = torch.randn(N, C, S, S, generator=g)
+    c0 = torch.randn(N, Cc, S, S, generator=g)
+    gs(cu(x0), cu(c0), torch.zeros(N, device="cuda"), False)  # data dependent init
     with torch.no_grad():
         for prm in gs.parameters():
             prm.add_(0.05 * torch.randn(prm.shape, generator=g).cuda())
     x = cu(x0).requires_grad_(True)
     c = cu(c0).requires_grad_(True)
-    y, ld = gs(x, c, torch.zeros(3, device="cuda"), False)
+    y, ld = gs(x, c, torch.zeros(N, device="cuda"), False)
     wgt = torch.randn(y.shape, generator=g)
-    gld = torch.tensor([0.7, -0.4, 1.3])
+    gld = torch.randn(N, generator=g)
     ((y * cu(wgt)).sum() + (ld * cu(gld)).sum()).backward()
     # oracle on the same parameters
     sd = {k: v.detach().cpu().clone().requires_grad_(v.is_floating_point()) for k, v in gs.state_dict().items()}
     xo = x0.clone().requires_grad_(True)
     co = c0.clone().requires_grad_(True)
-    yo, ldo = O.glowstep(sd, "", xo, co, torch.zeros(3), False, True)
+    yo, ldo = O.glowstep(sd, "", xo, co, torch.zeros(N), False, True)
     ((yo * wgt).sum() + (ldo * gld).sum()).backward()
     close(y, yo.detach(), 1e-4, 1e-5)
     close(ld, ldo.detach(), 1e-4, 1e-5)
-    close(x.grad, xo.grad, 2e-3, 1e-5)
-    close(c.grad, co.grad, 2e-3, 1e-5)
+    if Hd <= 64:
+        close(x.grad, xo.grad, 2e-3, 1e-5)
+        close(c.grad, co.grad, 2e-3, 1e-5)
+        for k, p in gs.named_parameters():
+            ref = sd[k].grad
+            torch.testing.assert_close(p.grad.cpu(), ref, rtol=3e-3, atol=3e-4 * float(ref.abs().max()) + 1e-6,
+                                       msg=lambda m: k + ": " + m)
+        return
+    # Millions of hidden activations: a handful sit within the arithmetic's 1e-5 of the LeakyReLU kink and take the other
+    # slope than the CPU run (checked: the outliers of the split-precision run are exactly the 3x3 neighbourhoods of
+    # the sign flips against the fp32 kernels, which themselves agree with the oracle to 1e-6 everywhere).  The
+    # derivative is discontinuous there, so gradients are compared in the L2 norm.
+    l2 = lambda u, v: float((u.detach().cpu().double() - v.double()).norm() / (v.double().norm() + 1e-30))
+    tol = 2e-5 if conv_precision == "f32" else 5e-3
+    assert l2(x.grad, xo.grad) < tol
+    assert l2(c.grad, co.grad) < tol
     for k, p in gs.named_parameters():
-        ref = sd[k].grad
-        torch.testing.assert_close(p.grad.cpu(), ref, rtol=3e-3, atol=3e-4 * float(ref.abs().max()) + 1e-6,
-                                   msg=lambda m: k + ": " + m)
+        assert l2(p.grad, sd[k].grad) < tol, (k, l2(p.grad, sd[k].grad))
 
 
 def test_flow_bijection_single_level():
