@@ -86,8 +86,8 @@ int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, i
  * glow_modules.py:139-142 + Utils/modules.py:8-19): with y = act((u+b)*exp(logs)) saved from the forward pass,
  *   g  = conv(gin, wpk)                    (wpk packed with transpose_flip = 1 / mode 1)
  *   out = g * act'(y) * exp(logs[c])       (= grad wrt u, what the producer's weight- and data-gradient consume)
- *   part[row][c][0] = Σ out,  part[row][c][1] = Σ g*y   over the pixels of partial-sum row `row`
- * so grad b = Σ_rows part[.,c,0] and grad logs = Σ_rows part[.,c,1] need only a tiny reduction afterwards.
+ *   part[row][0][c] = Σ out,  part[row][1][c] = Σ g*y   over the pixels of partial-sum row `row`
+ * so grad b = Σ_rows part[.,0,c] and grad logs = Σ_rows part[.,1,c] need only a tiny reduction afterwards.
  * rows = rfn_conv2d_dgrad_act_rows_bf16x3(N,H,W,ks,Cout,Cin); part holds rows*Cout*2 floats; Cout % 64 == 0. */
 int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout, int Cin);
 int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Cin, const float* wpk, const float* y, long y_ns,

@@ -30,7 +30,7 @@ struct ConvParams {
     // ep_mode 4 (data-gradient conv fused with the backward of the producer's ActNorm+activation epilogue):
     const float* ybuf;  // saved forward activation y = act((u+b)*exp(l)), same shape as the output
     long ybuf_ns;
-    float* part;        // [gridDim.x * WPX][Cout][2] per-wave partial sums: Σ gu, Σ g*y
+    float* part;        // [rows][2][Cout] partial sums: Σ gu, Σ g*y (rows: rfn_conv2d_dgrad_act_rows_bf16x3)
 };
 
 // Sum over each 32-lane half of a wave with DPP adds (VALU rate; __shfl_xor would go through the LDS crossbar, and the
@@ -111,9 +111,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                         dst[0] += sb;
                         dst[1] += sl;
                     } else {
-                        float* dst = p.part + ((long)prow * p.Cout + co_base + cidx + 4 * kk) * 2;
+                        float* dst = p.part + (long)prow * 2 * p.Cout + co_base + cidx + 4 * kk;  // [row][2][Cout]
                         dst[0] = sb;
-                        dst[1] = sl;
+                        dst[p.Cout] = sl;
                     }
                 }
             }

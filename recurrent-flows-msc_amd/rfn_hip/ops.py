@@ -133,13 +133,13 @@ def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks):
     gu = torch.empty((N, Cout, H, W), device=gin.device, dtype=torch.float32)
     up, uns = L.frames(gu, "gu")
     rows = L.load().rfn_conv2d_dgrad_act_rows_bf16x3(N, H, W, ks, Cout, Cin)
-    part = torch.empty((rows, Cout, 2), device=gin.device, dtype=torch.float32)
+    part = torch.empty((rows, 2, Cout), device=gin.device, dtype=torch.float32)
     L.call("rfn_conv2d_dgrad_act_bf16x3", gp, _l(gns), _i(Cin), L.dev(wpk_flip), yp, _l(yns), L.dev(logs), _i(act), up,
            _l(uns), L.dev(part), _i(Cout), _i(N), _i(H), _i(W), _i(ks),
            meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W, Cin, (H, W), True, True) + "+actbwd", 2.0 * N * H * W * Cin * Cout * ks * ks,
                  "N%d %d->%d %dx%d k%d dgrad+actbwd" % (N, Cin, Cout, H, W, ks),
                  4.0 * (N * H * W * (Cin + 2 * Cout) + Cin * Cout * ks * ks)))
-    sums = part.sum(0).t().contiguous()  # [2, Cout]: contiguous rows, which AccumulateGrad can keep without a copy
+    sums = part.sum(0)  # [2, Cout]: contiguous rows, which AccumulateGrad can keep without a copy
     return gu, sums[0], sums[1]
 
 
