@@ -20,7 +20,7 @@ import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-PKG = os.path.join(ROOT, "recurrent-flows-msc_amd")
+PKG = os.environ.get("RFN_PKG_DIR") or os.path.join(ROOT, "recurrent-flows-msc_amd")  # (override: A/B runs of two builds)
 for p in (ROOT, PKG):
     if p not in sys.path:
         sys.path.insert(0, p)
