@@ -242,3 +242,36 @@ def test_recurrent_param_net_deferred_weight_gradients():
     # norm layers other than "none" keep the plain path
     bn = SimpleParamNet([8], in_channels=4, out_channels=2, norm_type="batchnorm")
     assert bn.recurrent(force=True) == bn.raw
+
+
+def test_bench_roofline_groups_by_kernel_symbol():
+    """bench.kernel_roofline: the roofline line is per kernel SYMBOL (epilogue variants such as "+actbwd" are merged, as
+    rocprofv3 --stats groups them), the dominant kernel is the one with the most time among the MFMA kernels, and the
+    fractions are algorithmic bytes / FLOPs over time against the 8 TB/s and split-precision MFMA roofs."""
+    import importlib
+    bench = importlib.import_module("bench")
+
+    class Ev:
+        def __init__(self, t):
+            self.t = t
+
+        def elapsed_time(self, other):
+            return other.t - self.t
+
+    def rec(name, kind, sym, flops, nbytes, ms, shape="s"):
+        return (name, (kind, sym, flops, shape, nbytes), Ev(0.0), Ev(ms))
+    records = []
+    for _ in range(2):  # two "steps"
+        records += [rec("rfn_conv2d_fwd_bf16x3", "conv", "kernA", 1e12, 2e9, 1.0),
+                    rec("rfn_conv2d_dgrad_act_bf16x3", "conv", "kernA+actbwd", 1e12, 4e9, 1.5),
+                    rec("rfn_gemm_wgrad_bf16x3", "wgrad", "kernB", 3e12, 1e9, 2.0),
+                    ("rfn_squeeze2d_f32", None, Ev(0.0), Ev(0.25))]
+    roof, table = bench.kernel_roofline(records, 2)
+    assert roof["kernel"] == "kernA" and roof["launches_per_step"] == 2       # 2.5 ms/step beats kernB's 2.0
+    assert abs(roof["avg_launch_us"] - 1250.0) < 1e-6
+    assert abs(roof["hbm"]["achieved_GBps"] - 6e9 / 2.5e-3 / 1e9) < 1e-6      # (2e9 + 4e9) B in 2.5 ms
+    assert abs(roof["mfma"]["achieved_TFLOPs_fp32_equiv"] - 2e12 / 2.5e-3 / 1e12) < 1e-6
+    assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] <= 1.5
+    assert abs(roof["hip_kernel_ms_per_step"] - 4.75) < 1e-9
+    names = [r[0] for r in table["kernels"]]
+    assert "kernA" in names and "kernA+actbwd" in names and "rfn_squeeze2d_f32" in names
