@@ -18,6 +18,7 @@ from Flow.glow_modules import ActNorm
 from rfn_hip import ops as K
 from rfn_hip import debug as DBG
 from Utils import VGG_upscaler, VGG_downscaler, SimpleParamNet, ConvLSTM, free_bits_kl, batch_reduce
+from Utils.modules import recurrent_pair
 
 
 def kl_normal(q_mean, q_std, p_mean, p_std):
@@ -166,14 +167,14 @@ class RFN(nn.Module):
         base_t, noise_t = [], []
         # all 2(T-1) reparameterisation draws of the loop in one launch
         eps_all = None if draws is not None else torch.randn((T - 1, 2) + tuple(zprev.shape), device=dev)
-        enc_net, pri_net = self.encoder.recurrent(), self.prior.recurrent()  # weight gradients time-batched
+        both_nets = recurrent_pair(self.encoder, self.prior)  # weight gradients time-batched, layer pairs co-launched
         for i in range(1, T):
             ht = store_ht[i - 1]
             if self.enable_smoothing:
-                enc_raw = enc_net(torch.cat((store_at[i - 1], zxprev), dim=1))
+                enc_in = torch.cat((store_at[i - 1], zxprev), dim=1)
             else:
-                enc_raw = enc_net(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
-            pri_raw = pri_net(torch.cat((ht, zxprev if self.res_q else zprev), dim=1))
+                enc_in = torch.cat((ht, zxprev, self._last(feats[i])), dim=1)
+            enc_raw, pri_raw = both_nets(enc_in, torch.cat((ht, zxprev if self.res_q else zprev), dim=1))
             # chunk + softplus, res_q shift, both reparameterised draws and the KL in one kernel (RNG order: prior first)
             eps_p = eps_like(zprev) if eps_all is None else eps_all[i - 1, 0]
             eps_q = eps_like(zprev) if eps_all is None else eps_all[i - 1, 1]

@@ -409,6 +409,54 @@ class _StepDenseAct(torch.autograd.Function):
         return gx, None, None, None, None, None
 
 
+class _StepDenseActPair(torch.autograd.Function):
+    """_StepDenseAct for TWO independent layers (the encoder's and the prior's i-th layer of a timestep) in one launch
+    each way (rfn_smallmap_dense_pair_bf16x3)."""
+
+    @staticmethod
+    def forward(ctx, x0, w0, b0, st0, slope0, packs0, x1, w1, b1, st1, slope1, packs1):
+        x0, x1 = x0.contiguous(), x1.contiguous()
+        y0, y1 = K.smallmap_dense_pair(x0, packs0[0], int(w0.shape[0]), x1, packs1[0], int(w1.shape[0]), bias0=b0, bias1=b1,
+                                       slope_out0=slope0, slope_out1=slope1)
+        ctx.cfg = (st0, slope0, packs0, int(w0.shape[1]), st1, slope1, packs1, int(w1.shape[1]))
+        ctx.save_for_backward(x0, y0 if slope0 is not None else None, x1, y1 if slope1 is not None else None)
+        return y0, y1
+
+    @staticmethod
+    def backward(ctx, g0, g1):
+        x0, y0, x1, y1 = ctx.saved_tensors
+        st0, slope0, packs0, cin0, st1, slope1, packs1, cin1 = ctx.cfg
+        g0, g1 = g0.contiguous(), g1.contiguous()
+        gx0, gp0, gx1, gp1 = K.smallmap_dense_pair(g0, packs0[1], cin0, g1, packs1[1], cin1, y0=y0, y1=y1,
+                                                   slope_in0=slope0 or 0.0, slope_in1=slope1 or 0.0, want_a_out=True)
+        st0.xs.append(x0); st0.gs.append(gp0)
+        st1.xs.append(x1); st1.gs.append(gp1)
+        return gx0, None, None, None, None, None, gx1, None, None, None, None, None
+
+
+def recurrent_pair(net0, net1):
+    """`run(x0, x1) -> (net0.raw(x0), net1.raw(x1))` for two SimpleParamNets applied side by side once per timestep
+    (encoder and prior, RFN_new.py:167-179): when both take the dense small-map path and have the same number of
+    layers, layer i of both runs in ONE launch each way; otherwise the two `recurrent()` callables run one after the
+    other.  Weight gradients are time-batched either way (_WeightPort)."""
+    f0, f1 = net0.recurrent(), net1.recurrent()
+    p0, p1 = getattr(f0, "ports", None), getattr(f1, "ports", None)
+    if p0 is None or p1 is None or len(p0) != len(p1) or os.environ.get("RFN_PAIR_LAUNCH") == "0":
+        return lambda x0, x1: (f0(x0), f1(x1))
+
+    def run(x0, x1):
+        H, W = int(x0.shape[2]), int(x0.shape[3])
+        k0, k1 = f0.dense_packs(x0), f1.dense_packs(x1)
+        if k0 is None or k1 is None or tuple(x1.shape[2:]) != (H, W) or x0.shape[0] != x1.shape[0]:
+            return f0(x0), f1(x1)
+        for i in range(len(p0)):
+            w0, b0, st0, s0 = p0[i]
+            w1, b1, st1, s1 = p1[i]
+            x0, x1 = _StepDenseActPair.apply(x0, w0, b0, st0, s0, k0[i], x1, w1, b1, st1, s1, k1[i])
+        return x0, x1
+    return run
+
+
 class SimpleParamNet(nn.Module):
     """Utils/modules.py:216-244 — conv stack then a conv producing (loc, softplus(raw scale))."""
 
@@ -462,18 +510,25 @@ class SimpleParamNet(nn.Module):
 
         packs = {}
 
-        def run(x):
+        def dense_packs(x):
+            """packed (forward, data-gradient) matrices of every layer for x's map size, or None (dense path unusable)"""
             H, W = int(x.shape[2]), int(x.shape[3])
-            dense = x.is_cuda and all(K.smallmap_supported(c, H, W) for c, _ in convs)
-            if dense and (H, W) not in packs:  # once per loss evaluation: both products of every layer
+            if not (x.is_cuda and all(K.smallmap_supported(c, H, W) for c, _ in convs)):
+                return None
+            if (H, W) not in packs:  # once per loss evaluation: both products of every layer
                 packs[(H, W)] = [(K.smallmap_pack(c.weight, H, W, False), K.smallmap_pack(c.weight, H, W, True))
                                  for c, _ in convs]
+            return packs[(H, W)]
+
+        def run(x):
+            pk = dense_packs(x)
             for i, (w, b, st, slope) in enumerate(ports):
-                if dense:
-                    x = _StepDenseAct.apply(x, w, b, st, slope, packs[(H, W)][i])
+                if pk is not None:
+                    x = _StepDenseAct.apply(x, w, b, st, slope, pk[i])
                 else:
                     x = _StepConvAct.apply(x, w, b, st, slope)
             return x
+        run.ports, run.dense_packs = ports, dense_packs
         return run
 
     def forward(self, x):

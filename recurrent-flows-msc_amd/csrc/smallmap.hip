@@ -101,8 +101,7 @@ struct SmallmapParams {
 
 constexpr int SM_WAVES = 8;
 
-__global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const SmallmapParams p) {
-    __shared__ float red[SM_WAVES][32][33];
+__device__ __forceinline__ void smallmap_dense_body(const SmallmapParams& p, float (&red)[SM_WAVES][32][33]) {
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int l31 = lane & 31, kg = lane >> 5;
     const int tile = blockIdx.x, m0 = blockIdx.y * 32;
@@ -187,6 +186,23 @@ __global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const Sma
     }
 }
 
+__global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_kernel(const SmallmapParams p) {
+    __shared__ float red[SM_WAVES][32][33];
+    smallmap_dense_body(p, red);
+}
+
+// Two independent products in one launch (blockIdx.z): the encoder and the prior layer of a timestep have no data
+// dependence on each other, and a launch of this kernel is mostly latency.
+struct SmallmapPair {
+    SmallmapParams g[2];
+};
+__global__ __launch_bounds__(64 * SM_WAVES) void smallmap_dense_pair_kernel(const SmallmapPair pp) {
+    __shared__ float red[SM_WAVES][32][33];
+    const SmallmapParams& p = pp.g[blockIdx.z];
+    if ((int)blockIdx.x * 32 >= p.N || (int)blockIdx.y * 32 >= p.B) return;  // block-uniform: grid covers the larger one
+    smallmap_dense_body(p, red);
+}
+
 extern "C" int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float slope_in, const float* packed,
                                          const float* bias, const float* add, int act_out, float slope_out, float* out,
                                          float* a_out, int B, int K, int N, int HW, rfn_stream_t stream) {
@@ -202,6 +218,44 @@ extern "C" int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float s
     p.a_ns = K; p.K1 = K; p.out_ns = N; p.nsplit = N;
     dim3 grid((N + 31) / 32, (B + 31) / 32);
     hipLaunchKernelGGL(smallmap_dense_kernel, grid, dim3(64 * SM_WAVES), 0, (hipStream_t)stream, p);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+static int smallmap_fill(SmallmapParams& p, const float* a, const float* y, float slope_in, const float* packed,
+                         const float* bias, const float* add, int act_out, float slope_out, float* out, float* a_out, int B,
+                         int K, int N, int HW) {
+    if (!(a && packed && out && B > 0 && K > 0 && N > 0 && HW > 0 && HW <= 16)) return -1;
+    if (!(K % 8 == 0 && K % HW == 0 && N % HW == 0)) return -2;
+    if ((((uintptr_t)a | (uintptr_t)packed | (uintptr_t)(y ? y : a) | (uintptr_t)(a_out ? a_out : a)) & 15) != 0) return -3;
+    memset(&p, 0, sizeof(p));
+    p.a = a; p.y = y; p.slope_in = slope_in; p.packed = reinterpret_cast<const bf16x8*>(packed); p.bias = bias; p.add = add;
+    p.act_out = act_out; p.slope_out = slope_out; p.out = out; p.a_out = a_out;
+    p.B = B; p.K = K; p.N = N; p.HW = HW; p.KS = (K + 15) / 16;
+    p.a_ns = K; p.K1 = K; p.out_ns = N; p.nsplit = N;
+    return 0;
+}
+
+// rfn_smallmap_dense_bf16x3 twice in one launch (suffix 0 / 1): two products without a data dependence, same B and HW.
+extern "C" int rfn_smallmap_dense_pair_bf16x3(const float* a0, const float* y0, float slope_in0, const float* packed0,
+                                              const float* bias0, int act_out0, float slope_out0, float* out0,
+                                              float* a_out0, int K0, int N0, const float* a1, const float* y1,
+                                              float slope_in1, const float* packed1, const float* bias1, int act_out1,
+                                              float slope_out1, float* out1, float* a_out1, int K1, int N1, int B, int HW,
+                                              rfn_stream_t stream) {
+    if (B == 0) return 0;
+    SmallmapPair pp;
+    int rc = smallmap_fill(pp.g[0], a0, y0, slope_in0, packed0, bias0, nullptr, act_out0, slope_out0, out0, a_out0, B, K0,
+                           N0, HW);
+    if (!rc) rc = smallmap_fill(pp.g[1], a1, y1, slope_in1, packed1, bias1, nullptr, act_out1, slope_out1, out1, a_out1, B,
+                                K1, N1, HW);
+    if (rc) {
+        rfn_set_error("rfn_smallmap_dense_pair_bf16x3: argument check failed (%d)", rc);
+        return rc;
+    }
+    const int Nmax = N0 > N1 ? N0 : N1;
+    dim3 grid((Nmax + 31) / 32, (B + 31) / 32, 2);
+    hipLaunchKernelGGL(smallmap_dense_pair_kernel, grid, dim3(64 * SM_WAVES), 0, (hipStream_t)stream, pp);
     RFN_LAUNCH_CHECK();
     return 0;
 }

@@ -656,6 +656,32 @@ def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slo
     return (out, a_out) if want_a_out else out
 
 
+def smallmap_dense_pair(a0, packed0, n_ch0, a1, packed1, n_ch1, bias0=None, bias1=None, slope_out0=None, slope_out1=None,
+                        y0=None, y1=None, slope_in0=0.0, slope_in1=0.0, want_a_out=False):
+    """two independent smallmap_dense products in ONE launch (rfn_smallmap_dense_pair_bf16x3): same batch and map size.
+    Returns (out0, out1) or (out0, a0', out1, a1') with want_a_out."""
+    a0, a1 = a0.contiguous(), a1.contiguous()
+    B, H, W = int(a0.shape[0]), int(a0.shape[2]), int(a0.shape[3])
+    assert int(a1.shape[0]) == B and tuple(a1.shape[2:]) == (H, W)
+    HW = H * W
+    K0, K1 = int(a0.shape[1]) * HW, int(a1.shape[1]) * HW
+    out0 = torch.empty((B, n_ch0, H, W), device=a0.device, dtype=torch.float32)
+    out1 = torch.empty((B, n_ch1, H, W), device=a0.device, dtype=torch.float32)
+    ao0 = torch.empty_like(a0) if want_a_out and y0 is not None else None
+    ao1 = torch.empty_like(a1) if want_a_out and y1 is not None else None
+    y0c = None if y0 is None else y0.contiguous()  # held until the launch is enqueued
+    y1c = None if y1 is None else y1.contiguous()
+    fl = ctypes.c_float
+    L.call("rfn_smallmap_dense_pair_bf16x3",
+           L.dev(a0), L.dev(y0c), fl(slope_in0), L.dev(packed0), L.dev(bias0), _i(0 if slope_out0 is None else 1),
+           fl(0.0 if slope_out0 is None else slope_out0), L.dev(out0), L.dev(ao0), _i(K0), _i(n_ch0 * HW),
+           L.dev(a1), L.dev(y1c), fl(slope_in1), L.dev(packed1), L.dev(bias1), _i(0 if slope_out1 is None else 1),
+           fl(0.0 if slope_out1 is None else slope_out1), L.dev(out1), L.dev(ao1), _i(K1), _i(n_ch1 * HW), _i(B), _i(HW))
+    if want_a_out:
+        return out0, (ao0 if ao0 is not None else a0), out1, (ao1 if ao1 is not None else a1)
+    return out0, out1
+
+
 def smallmap_conv_ok(H, W, C1, C2, Cout, N):
     """3x3 conv on a map small enough for the dense kernels (rfn_smallmap_conv_bf16x3), and few enough frames: every
     32-frame row tile streams the whole dense matrix ((C1+C2)*HW x Cout*HW, on a 4x4 map more than half structural

@@ -292,6 +292,32 @@ def test_smallmap_dense_conv_fwd_bwd(K, B, Cin, Cout, H, W, slope):
     assert relerr(gx, x.grad) < 2e-5
 
 
+def test_smallmap_dense_pair_equals_two_single_launches(K):
+    """rfn_smallmap_dense_pair_bf16x3 (encoder and prior layer of a timestep in one launch) against two
+    rfn_smallmap_dense_bf16x3 launches: forward with bias + leaky_relu, and the data gradient with activation backward."""
+    if K.CONV_PRECISION != "bf16x3":
+        pytest.skip("split-precision kernels only")
+    g = torch.Generator().manual_seed(95)
+    B, H, W = 32, 2, 2
+    shapes = [(768, 256), (256, 112)]
+    xs = [cu(torch.randn(B, ci, H, W, generator=g)) for ci, _ in shapes]
+    ws = [cu(torch.randn(co, ci, 3, 3, generator=g) / (3 * ci ** 0.5)) for ci, co in shapes]
+    bs = [cu(torch.randn(co, generator=g)) for _, co in shapes]
+    pf = [K.smallmap_pack(w, H, W, False) for w in ws]
+    pb = [K.smallmap_pack(w, H, W, True) for w in ws]
+    y0, y1 = K.smallmap_dense_pair(xs[0], pf[0], 256, xs[1], pf[1], 112, bias0=bs[0], bias1=bs[1], slope_out0=0.2,
+                                   slope_out1=None)
+    r0 = K.smallmap_dense(xs[0], pf[0], 256, bias=bs[0], slope_out=0.2)
+    r1 = K.smallmap_dense(xs[1], pf[1], 112, bias=bs[1])
+    assert torch.equal(y0, r0) and torch.equal(y1, r1)
+    g0, g1 = cu(torch.randn(B, 256, H, W, generator=g)), cu(torch.randn(B, 112, H, W, generator=g))
+    gx0, gp0, gx1, gp1 = K.smallmap_dense_pair(g0, pb[0], 768, g1, pb[1], 256, y0=y0, y1=None, slope_in0=0.2,
+                                               want_a_out=True)
+    s0, sp0 = K.smallmap_dense(g0, pb[0], 768, y=y0, slope_in=0.2, want_a_out=True)
+    s1 = K.smallmap_dense(g1, pb[1], 256)
+    assert torch.equal(gx0, s0) and torch.equal(gp0, sp0) and torch.equal(gx1, s1) and gp1 is g1
+
+
 @pytest.mark.parametrize("N,C1,C2,Cout,H,W,ep_mode,act,split", [(70, 32, 256, 256, 2, 2, 1, 2, None),
                                                                  (40, 16, 24, 64, 4, 4, 1, 1, None),
                                                                  (33, 256, 0, 64, 2, 2, 2, 0, None),
