@@ -105,6 +105,33 @@ typedef struct {
 } rfn_pack_desc;
 int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_stream_t stream);
 
+/* ---- a5 fused  AffineCoupling.net forward for the shallow levels (Flow/glow_modules.py:232-238 with :119-121 and
+ * :139-142), csrc/coupling_po.hip: conv3x3 -> ActNorm -> act -> conv1x1 -> ActNorm -> act -> tap-expanded conv3x3 in
+ * ONE kernel; the 256-channel hidden activations pass from layer to layer in registers (they are still written once:
+ * the backward pass needs them).  Hidden layers: three bf16 pieces per operand, six MFMAs per product, fp32 accumulate
+ * (fp32-equivalent); last layer: two pieces.
+ *   rfn_coupling_po_supported  1 when (N, C, Cc, Hd, H, W) is a shape the kernel takes (else use the unfused kernels);
+ *   rfn_coupling_po_packed_bytes / rfn_coupling_po_pack  the fragment-ordered weight stream of one coupling net
+ *       (descs_device: device array of n rfn_po_pack_desc; one launch packs every net of a flow);
+ *   rfn_coupling_po_fwd  z: output of ActNorm+InvConv [N, >=C/2, H, W] (channels [0, C/2) are read), cond [N, Cc, H, W];
+ *       n1b/n1l, n2b/n2l: ActNorm bias / logs [256] of the hidden layers; act 0 none, 1 relu, 2 leaky .2.
+ *       Outputs h1, h2 [N, 256, H, W] and P [N, 9C, H, W], P[tap*C + co] = sum_c w3[co][c][tap] h2[c]
+ *       (rfn_tap_gather_f32 turns P into the Conv2dZeros output). */
+typedef struct {
+    const float* w1;  /* [256][C/2 + Cc][3][3] */
+    const float* w2;  /* [256][256][1][1] */
+    const float* w3;  /* [C][256][3][3] */
+    float* dst;       /* rfn_coupling_po_packed_bytes(Cin, C) bytes, 16-byte aligned */
+    int Cin, C;
+} rfn_po_pack_desc;
+int rfn_coupling_po_supported(int N, int C, int Cc, int Hd, int H, int W);
+long rfn_coupling_po_packed_bytes(int Cin, int C);
+int rfn_coupling_po_pack(const void* descs_device, int n, rfn_stream_t stream);
+int rfn_coupling_po_fwd(const float* z, long z_ns, const float* cond, long cond_ns, const void* wpk, const float* n1b,
+                        const float* n1l, const float* n2b, const float* n2l, float* h1, long h1_ns, float* h2,
+                        long h2_ns, float* P, long P_ns, int N, int C, int Cc, int H, int W, int act,
+                        rfn_stream_t stream);
+
 /* Split-precision weight-gradient GEMM: gw[M][Nc] += Σ_{f,p} a[f][m][p] * b[f][n][p]  (a: [F,M,HW] frame stride a_ns,
  * b: [F,Nc,HW] frame stride b_ns; HW % 4 == 0, 16-byte aligned bases).  gw is accumulated with float atomics (caller
  * zeroes it).  1x1 weight gradients use it directly (a = output grad, b = conv input); 3x3 ones first expand the

@@ -160,31 +160,57 @@ class ListGlow(nn.Module):
         W = torch.matmul(p, torch.matmul(L, U))
         return W, log_s.sum() * hw
 
-    def _packed_weights(self):
-        """one launch re-packs (and hi/lo splits) every coupling-net weight of the flow, forward and data-gradient
-        orientation; returns {GlowStep: (w1 f, w1 d, w2 f, w2 d, w3 f, w3 d)} or None (fp32 arithmetic / CPU)."""
-        if K.CONV_PRECISION != "bf16x3":
+    def _packed_weights(self, x_shape, condition):
+        """two launches re-pack every coupling-net weight of the flow: the split-precision (bf16x3) packs of the
+        data-gradient convolutions -- and of the forward convolutions where bf16x3 is the forward arithmetic -- and the
+        fragment streams of the fused forward kernel (shallow levels, 'mixed' arithmetic).
+        Returns {GlowStep: (w1 f, w1 d, w2 f, w2 d, w3 f, w3 d, fused stream)} (entries None where unused) or None."""
+        if not K.bwd_b3():
             return None
-        steps = [s for _, ss, _ in self._level_steps() for s in ss]
-        items = []
-        for s in steps:
-            n0, n2, n4 = s.affine.net[0], s.affine.net[2], s.affine.net[4]
-            w3 = n4.conv.weight
-            items += [(n0.conv.weight, 0), (n0.conv.weight, 1), (n2.conv.weight, 0), (n2.conv.weight, 1),
-                      (w3, 2 if K.zeros_conv_uses_taps(w3) else 0), (w3, 1)]
-        if not items or not items[0][0].is_cuda:
+        levels = self._level_steps()
+        if not levels or not levels[0][1] or not levels[0][1][0].affine.net[0].conv.weight.is_cuda:
             return None
+        N, C, H, W = (int(v) for v in x_shape)
+        items, nets, slots = [], [], {}
+        for l, (_, steps, split) in enumerate(levels):
+            C, H, W = C * 4, H // 2, W // 2
+            Cc = int(condition[l].shape[1])
+            for s in steps:
+                n0, n2, n4 = s.affine.net[0], s.affine.net[2], s.affine.net[4]
+                w1, w2, w3 = n0.conv.weight, n2.conv.weight, n4.conv.weight
+                fused = s.flow_norm != "batchnorm" and int(w2.shape[2]) == 1 and \
+                    K.coupling_po_ok(N, C, Cc, int(w1.shape[0]), H, W, w1, w3)
+                b3fwd = not fused and K.fwd_prec(H, W) == "bf16x3"
+                slot = [None] * 7
+                for j, (w, mode) in enumerate(((w1, 0), (w1, 1), (w2, 0), (w2, 1),
+                                               (w3, 2 if K.zeros_conv_uses_taps(w3) else 0), (w3, 1))):
+                    if j % 2 == 1 or b3fwd:
+                        slot[j] = len(items)
+                        items.append((w, mode))
+                if fused:
+                    slot[6] = len(nets)
+                    nets.append((w1, w2, w3))
+                slots[s] = slot
+            if split is not None:
+                C = C // 2
         plan = getattr(self, "_pack_plan", None)
         if plan is None or not plan.valid_for(items):
             plan = self._pack_plan = K.PackPlan(items)
         plan.run()
-        return {s: tuple(plan.bufs[6 * i:6 * i + 6]) for i, s in enumerate(steps)}
+        po = None
+        if nets:
+            po = getattr(self, "_po_plan", None)
+            if po is None or not po.valid_for(nets):
+                po = self._po_plan = K.POPackPlan(nets)
+            po.run()
+        return {s: tuple((None if i is None else plan.bufs[i]) for i in sl[:6]) + ((None if sl[6] is None else po.bufs[sl[6]]),)
+                for s, sl in slots.items()}
 
     def f(self, x, condition, logdet):
         """Flow/glow.py:105-117 (same order of operations; per-level batching of the tiny parameter algebra)."""
         z = x
         dls, const = [], 0
-        packs = self._packed_weights()
+        packs = self._packed_weights(x.shape, condition)
         for l, (squeeze, steps, split) in enumerate(self._level_steps()):
             z = squeeze(z, undo_squeeze=False)
             W, c = self._batched_invconv(steps, z.shape[2] * z.shape[3])

@@ -1,0 +1,703 @@
+// Fused coupling network for the shallow flow levels ("pixel-owning" layout), fp32-grade split arithmetic on f16 MFMA.
+//
+// Reference op sequence (Flow/glow_modules.py:232-238, 119-121, 139-142):
+//     h1 = act(ActNorm(conv3x3(cat(z1, cond))))      Cin = C/2 + Cc  ->  Hd = 256
+//     h2 = act(ActNorm(conv1x1(h1)))                  256 -> 256
+//     o  = (conv3x3(h2) + b3) * exp(3 logs3)          256 -> C
+// The unfused kernels (conv_bf16x3.hip) own OUTPUT-CHANNEL slabs per wave and pass the 256-channel hidden tensors
+// through HBM (level 0: 637 MB each, written once and read once or twice per layer).  Here a wave owns 32 PIXELS and
+// carries them through the whole chain:
+//   * an MFMA 32x32 accumulator tile D[channel][pixel] has the pixel on the lane and 16 channels in registers, which is
+//     exactly the B-operand layout of the next 32x32x16 MFMA whose K runs over those channels (MI355X guide: "an
+//     accumulator tile as the next MFMA's operand"; the k order inside a step is permuted, so the 1x1 weights are
+//     packed in that order).  h1 / h2 never leave the register file on their way to the next layer;
+//   * conv2 runs K-MAJOR: as soon as four h1 tiles (128 channels) exist they are converted and multiplied into all
+//     eight conv2 accumulators (8 independent MFMA chains), so h1 needs no storage at all and h2 = the 8 accumulators;
+//   * the weights are the shared operand: every wave of every workgroup streams the same pre-split, fragment-ordered
+//     weight groups from L2 into LDS with LDS-DMA (global_load_lds_dwordx4), two groups ahead in a ring of three
+//     slots behind counted vmcnt waits;
+//     A fragments are single conflict-free ds_read_b128;
+//   * the first 3x3 convolution reads its im2col B fragments from a haloed, pre-split image of the workgroup's 128
+//     pixels (z1 | cond, a few KB) staged in LDS once per round -- loaded and converted one round ahead;
+//   * the last 3x3 convolution runs tap-expanded: P[tap*C + co][pixel] = Σ_c w3[co][c][tap] h2[c][pixel] is one more
+//     1x1 product on the register-resident h2 (9C <= 96 rows), and the cross-pixel part o[co] = Σ_tap P[tap,co][px+tap]
+//     is left to the gather kernel (shell.hip) -- 9C floats per pixel instead of the 256-channel h2.
+// h1 and h2 are still WRITTEN once (the backward pass needs them); they are never read back in the forward pass.
+//
+// Arithmetic ("f16x3s").  bits/dim parity (north_star: 1e-4) is decided by the forward pass, and two bf16 pieces per
+// operand ("bf16x3", 16 significant bits) are measurably not enough when the flow is ill-conditioned
+// (tools/precision_study.py, canonical model at T=10: 1e-4..5e-4 against 1e-5 for fp32).  This kernel splits every
+// operand into two FP16 pieces after an exact power-of-two scaling,
+//     x * 2^e = hi + lo,   hi = fp16(x 2^e),  lo = fp16(x 2^e - hi)        (22 significant bits),
+// and forms a*b as  hi*hi + hi*lo + lo*hi  with three v_mfma_f32_32x32x16_f16 accumulating in fp32; the scale is undone
+// in the epilogue.  Same MFMA count as bf16x3, error at the fp32 level (study: 1.0e-5 vs 1.1e-5 for a 3-piece / 6-MFMA
+// bf16 split).  fp16 has 5 exponent bits, so the scales are dynamic and chosen where the data is:
+//     weights        one scale per convolution, max|w| -> [2^14, 2^15)            (pack kernel)
+//     conv1 input    one scale per round (block maximum of the staged image)
+//     h1 -> conv2    per PIXEL (lane): running maximum over the h1 tiles produced so far; when a later tile raises it,
+//                    the eight conv2 accumulators of that pixel are rescaled by the (exact) power of two
+//     h2 -> conv3    per pixel, maximum over all 256 channels (all of h2 is in registers before conv3 starts)
+#include "conv_common.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+#define PO_HD 256          // hidden width (8 output tiles of 32)
+#define PO_TAP_PAIRS 5     // 9 taps in pairs (the lane half selects the tap of a pair); the 10th tap is zero weight
+#define PO_WAVES 4
+#define PO_ROUND_PX (32 * PO_WAVES)
+#define PO_ITEMS 4         // staging items per thread (NG * IPOS <= 1024)
+
+// ---- geometry of the forward weight stream (host + device).  Unit: fragment = 64 lanes x 16 B = 1 KB; two planes
+// (hi, lo) per logical fragment.  Fragment 0 is a header: floats {1/s_w1, 1/s_w2, 1/s_w3}.  Then, consumed in order:
+//   for quad u = 0, 1  (conv1 output tiles 4u .. 4u+3):
+//       NG conv1 groups of 5 k-steps:   ((k*4 + t)*2 + plane)                                    40 fragments
+//       4 conv2 groups of 2 k-steps (h1 k-steps 8u + 2g + {0,1}, all 8 output tiles):
+//                                        ((k*8 + a2)*2 + plane)                                  32 fragments
+//   4 conv3 groups of 4 k-steps:         ((k*NP + jt)*2 + plane)                                 8 NP fragments
+struct POGeom {
+    int NG, NP, NS1;
+    int quad_frags;    // fragments per quad
+    int c3;            // first fragment of the conv3 part
+    int total_frags;
+};
+__host__ __device__ static inline POGeom po_geom(int Cin, int C) {
+    POGeom g;
+    g.NG = (Cin + 7) / 8;
+    g.NP = (9 * C + 31) / 32;
+    g.NS1 = PO_TAP_PAIRS * g.NG;
+    g.quad_frags = g.NG * 40 + 4 * 32;
+    g.c3 = 1 + 2 * g.quad_frags;
+    g.total_frags = g.c3 + 4 * 8 * g.NP;
+    return g;
+}
+
+// group `idx` (0 .. 2 NG + 11) of a round in consumption order: first fragment and fragment count
+__host__ __device__ constexpr int po_group_base(int NG, int NP, int idx) {
+    const int QF = NG * 40 + 128;
+    return idx < NG ? 1 + idx * 40
+         : idx < NG + 4 ? 1 + NG * 40 + (idx - NG) * 32
+         : idx < 2 * NG + 4 ? 1 + QF + (idx - NG - 4) * 40
+         : idx < 2 * NG + 8 ? 1 + QF + NG * 40 + (idx - 2 * NG - 4) * 32
+         : 1 + 2 * QF + (idx - 2 * NG - 8) * 8 * NP;
+}
+__host__ __device__ constexpr int po_group_size(int NG, int NP, int idx) {
+    return idx < NG ? 40 : idx < NG + 4 ? 32 : idx < 2 * NG + 4 ? 40 : idx < 2 * NG + 8 ? 32 : 8 * NP;
+}
+
+// ------------------------------------------------------------------------------------------------ weight stream
+// One fragment: lane (r = lane & 31, kk = lane >> 5) holds A[row r][8 k-values] of one plane of the scaled weights.
+//   conv1 tile a (a < 8), k-step s = tp*NG + g:   row = 32a + r, tap = 2tp + kk, element j <-> input channel 8g + j
+//       (zero beyond Cin / tap 9)                                                   value w1[row][ci][tap]
+//   conv2 tile a2, k-step s < 16:  row = 32a2 + r, element j <-> h1 channel 16s + 8(j>>2) + 4kk + (j&3)
+//       (the register order of an accumulator tile)                                value w2[row][c1]
+//   conv3 row tile jt, k-step s < 16:  row R = 32jt + r = tap*C + co (zero beyond 9C), element j <-> h2 channel
+//       16s + 8(j>>2) + 4kk + (j&3)                                                 value w3[co][c2][tap]
+struct POPackDesc {   // mirrors rfn_po_pack_desc in include/rfn_hip.h
+    const float* w1;  // [256][Cin][3][3]
+    const float* w2;  // [256][256][1][1]
+    const float* w3;  // [C][256][3][3]
+    float* dst;       // total_frags * 1 KB
+    int Cin, C;
+};
+
+// exact power-of-two scale that puts m = max|x| into [2^14, 2^15) (fp16: largest finite 65504), and its inverse
+__host__ __device__ static inline void po_scale_for_max(float m, float* sc, float* inv) {
+    unsigned bits;
+    memcpy(&bits, &m, 4);
+    int E = (int)((bits >> 23) & 0xff);
+    if (E < 40) E = 40;          // zero / denormal-small maxima: any moderate scale does
+    if (E > 250) E = 250;        // inf / nan input: results are garbage either way
+    const unsigned sb = (unsigned)(268 - E) << 23, ib = (unsigned)(E - 14) << 23;
+    memcpy(sc, &sb, 4);
+    memcpy(inv, &ib, 4);
+}
+
+__device__ __forceinline__ void po_split_f16(const float (&v)[8], const float sc, f16x8& hi, f16x8& lo) {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        const float x = v[j] * sc;
+        const _Float16 h = (_Float16)x;
+        hi[j] = h;
+        lo[j] = (_Float16)(x - (float)h);
+    }
+}
+
+// grid (3, n): block (c, d) = max |w| of convolution c of descriptor d -> header {1/s_w1, 1/s_w2, 1/s_w3}
+__global__ __launch_bounds__(256) void po_pack_scale_kernel(const POPackDesc* __restrict__ descs) {
+    __shared__ float sm[4];
+    const POPackDesc d = descs[blockIdx.y];
+    const int c = blockIdx.x;
+    const float* w = c == 0 ? d.w1 : (c == 1 ? d.w2 : d.w3);
+    const long n = c == 0 ? (long)PO_HD * d.Cin * 9 : (c == 1 ? (long)PO_HD * PO_HD : (long)d.C * PO_HD * 9);
+    float m = 0.f;
+    for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) m = fmaxf(m, __shfl_xor(m, off, 64));
+    if ((threadIdx.x & 63) == 0) sm[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        m = fmaxf(fmaxf(sm[0], sm[1]), fmaxf(sm[2], sm[3]));
+        float sc, inv;
+        po_scale_for_max(m, &sc, &inv);
+        d.dst[c] = inv;
+    }
+}
+
+__global__ __launch_bounds__(256) void po_pack_fwd_kernel(const POPackDesc* __restrict__ descs) {
+    const POPackDesc d = descs[blockIdx.y];
+    const POGeom g = po_geom(d.Cin, d.C);
+    f16x8* dst = reinterpret_cast<f16x8*>(d.dst);
+    float scw[3];
+#pragma unroll
+    for (int c = 0; c < 3; ++c) scw[c] = 1.0f / d.dst[c];   // written by po_pack_scale_kernel (exact powers of two)
+    // one thread per (item, lane); item = one k-step of one row tile of one of the three products (2 planes)
+    const int n1 = 8 * g.NS1, n2 = 8 * 16, n3 = g.NP * 16;
+    const long n_items = (long)(n1 + n2 + n3) * 64;
+    for (long it = (long)blockIdx.x * blockDim.x + threadIdx.x; it < n_items; it += (long)gridDim.x * blockDim.x) {
+        const int lane = (int)(it & 63);
+        int k = (int)(it >> 6);
+        const int r = lane & 31, kk = lane >> 5;
+        float v[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = 0.f;
+        long frag0;
+        float sc;
+        if (k < n1) {
+            const int a = k / g.NS1, s = k % g.NS1;
+            frag0 = 1 + (long)(a >> 2) * g.quad_frags + (s / 5) * 40 + ((s % 5) * 4 + (a & 3)) * 2;
+            sc = scw[0];
+            const int tp = s / g.NG, gg = s % g.NG, tap = 2 * tp + kk;
+            if (tap < 9) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int ci = 8 * gg + j;
+                    if (ci < d.Cin) v[j] = d.w1[((long)(32 * a + r) * d.Cin + ci) * 9 + tap];
+                }
+            }
+        } else if (k < n1 + n2) {
+            k -= n1;
+            const int a2 = k >> 4, s = k & 15;
+            frag0 = 1 + (long)(s >> 3) * g.quad_frags + g.NG * 40 + ((s & 7) >> 1) * 32 + ((s & 1) * 8 + a2) * 2;
+            sc = scw[1];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int c1 = 16 * s + 8 * (j >> 2) + 4 * kk + (j & 3);
+                v[j] = d.w2[(long)(32 * a2 + r) * PO_HD + c1];
+            }
+        } else {
+            k -= n1 + n2;
+            const int jt = k >> 4, s = k & 15;
+            frag0 = g.c3 + (long)(s >> 2) * (8 * g.NP) + ((s & 3) * g.NP + jt) * 2;
+            sc = scw[2];
+            const int R = 32 * jt + r;
+            if (R < 9 * d.C) {
+                const int tap = R / d.C, co = R % d.C;
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const int c2 = 16 * s + 8 * (j >> 2) + 4 * kk + (j & 3);
+                    v[j] = d.w3[((long)co * PO_HD + c2) * 9 + tap];
+                }
+            }
+        }
+        f16x8 hi, lo;
+        po_split_f16(v, sc, hi, lo);
+        dst[frag0 * 64 + lane] = hi;
+        dst[(frag0 + 1) * 64 + lane] = lo;
+    }
+}
+
+extern "C" long rfn_coupling_po_packed_bytes(int Cin, int C) { return (long)po_geom(Cin, C).total_frags * 1024; }
+
+extern "C" int rfn_coupling_po_pack(const void* descs_device, int n, rfn_stream_t stream) {
+    RFN_CHECK_ARG(descs_device && n >= 0, -1);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(po_pack_scale_kernel, dim3(3, n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const POPackDesc*>(descs_device));
+    hipLaunchKernelGGL(po_pack_fwd_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const POPackDesc*>(descs_device));
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ------------------------------------------------------------------------------------------------ forward kernel
+struct POFwdParams {
+    const float* z;     long z_ns;      // [N, >=Ch, H, W]: conv1 reads channels [0, Ch)
+    const float* cond;  long cond_ns;   // [N, Cc, H, W]
+    const unsigned char* wpk;           // forward weight stream (po_pack_fwd_kernel)
+    const float* n1b; const float* n1l; const float* n2b; const float* n2l;   // ActNorm (bias, logs) of the hidden layers
+    float* h1; long h1_ns; float* h2; long h2_ns;   // [N, 256, H, W] saved activations
+    float* P;  long P_ns;                           // [N, 9C, H, W] tap-expanded conv3 output (no bias / scale)
+    int Ch, Cc, C, N, H, W, logW, act;
+    int rpf_shift;   // log2(rounds per frame), a round = 128 consecutive pixels of one frame
+    int n_rounds;    // N * H * W / 128
+    int IW, IPOS;    // haloed image of a round: (128/W + 2) rows x (W + 2) columns
+};
+
+#define PO_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
+
+template <int N>
+__device__ __forceinline__ void po_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory"); }
+
+// one 32-channel x 32-pixel accumulator tile: v = act((acc * u + bias) * exp(logs)) in place, fp32 store of the 16
+// values of this lane (channels 4kk + 8q + i of the tile at this lane's pixel), running max of |v|.
+// pb -> bias of the tile's first channel of this lane half (exp(logs) 256 floats further);
+// rsrc / voff: buffer descriptor of the output tensor and this lane's byte offset of (frame, first channel, pixel).
+template <int ACT>
+__device__ __forceinline__ void po_epilogue(f32x16& acc, const float u, const float* pb, const __amdgpu_buffer_rsrc_t rsrc,
+                                            const unsigned voff, const unsigned ch_bytes, float& vmax) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 8 * q);
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(pb + 256 + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = fmaf(acc[4 * q + i], u, b4[i]) * e4[i];
+            if (ACT == 1) t = fmaxf(t, 0.f);
+            if (ACT == 2) t = fmaxf(t, 0.2f * t);
+            acc[4 * q + i] = t;
+            vmax = fmaxf(vmax, fabsf(t));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rsrc, voff, (8 * q + i) * ch_bytes, 0);
+        }
+    }
+}
+
+// biased exponent of the power-of-two scale for a maximum m (see po_scale_for_max): scale = 2^(141 - E), clamped
+__device__ __forceinline__ int po_exp_of(const float m) {
+    int E = (int)((__float_as_uint(m) >> 23) & 0xff);
+    E = E < 40 ? 40 : E;
+    return E > 250 ? 250 : E;
+}
+
+template <int NG, int NP, int LOGW, int ACT>
+__global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const POFwdParams p) {
+    // square maps of side W = 2^LOGW: a round is 128 / W image rows; its haloed image has IW columns, IPOS positions
+    constexpr int W = 1 << LOGW, HW = W * W, IW = W + 2, IPOS = (PO_ROUND_PX / W + 2) * IW;
+    constexpr int RPF_SHIFT = 2 * LOGW - 7;   // log2(rounds per frame)
+    constexpr int G3 = 8 * NP;                 // fragments per conv3 group
+    constexpr int SLOTF = 40 > G3 ? 40 : G3;
+    constexpr int SLOT = SLOTF * 1024;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int NGRP = 2 * NG + 12;                                      // weight groups per round
+    float* par = reinterpret_cast<float*>(lds + 3 * SLOT);                 // [4][256]: b1, exp(l1), b2, exp(l2)
+    float* red = par + 1024;                                               // [8] block reductions
+    f16x8* img = reinterpret_cast<f16x8*>(lds + 3 * SLOT + 4096 + 64);      // [plane 2][NG][IPOS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int Cin = p.Ch + p.Cc;
+    constexpr unsigned ch_bytes = (unsigned)HW * 4u;
+
+    for (int c = tid; c < 256; c += 64 * PO_WAVES) {
+        par[c] = p.n1b[c];
+        par[256 + c] = expf(p.n1l[c]);
+        par[512 + c] = p.n2b[c];
+        par[768 + c] = expf(p.n2l[c]);
+    }
+    const float* hdr = reinterpret_cast<const float*>(p.wpk);
+    const float inv_w1 = hdr[0], inv_w2 = hdr[1], inv_w3 = hdr[2];
+    __syncthreads();
+
+    int sl = 2;   // LDS slot of the group being consumed (0 -> 1 -> 2 -> 0 at every group boundary)
+    // LDS-DMA of `nfr` fragments starting at stream fragment `base` into slot `slot`: wave w moves w, w+4, ...
+    auto dma = [&](const int base, const int nfr, const int slot) {
+        const unsigned char* src = p.wpk + (long)(base + wave) * 1024 + lane * 16;
+        unsigned char* dst = lds + slot * SLOT + wave * 1024;
+        for (int i = wave; i < nfr; i += PO_WAVES, src += PO_WAVES * 1024, dst += PO_WAVES * 1024)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                             (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    };
+    // Boundary into group IDX of the round.  The ring holds the group being consumed, the next one (landing) and the one
+    // after it, whose DMA is issued here into the slot everybody has just left.  Counted wait: YOUNGER = a lower bound of
+    // the vector-memory operations this wave issued after the DMA of group IDX (the DMA of group IDX+1 = a quarter of its
+    // fragments, plus activation stores; capped by the 6-bit counter) -- then my share of group IDX has landed; the
+    // barrier makes that everybody's share.
+#define PO_BOUNDARY(IDX, YOUNGER)                                                                          \
+    do {                                                                                                   \
+        po_wait_vm<(YOUNGER) < 63 ? (YOUNGER) : 63>();                                                     \
+        __builtin_amdgcn_s_barrier();                                                                      \
+        const int free_slot = sl;                                                                          \
+        sl = sl == 2 ? 0 : sl + 1;                                                                         \
+        const int n2_ = (IDX) + 2;                                                                         \
+        if (n2_ < NGRP) dma(po_group_base(NG, NP, n2_), po_group_size(NG, NP, n2_), free_slot);            \
+        else if (more) dma(po_group_base(NG, NP, n2_ - NGRP), po_group_size(NG, NP, n2_ - NGRP), free_slot); \
+    } while (0)
+
+    const auto rs_h1 = __builtin_amdgcn_make_buffer_rsrc(p.h1, 0, 0xFFFFFFFFu, 0x00020000);
+    const auto rs_h2 = __builtin_amdgcn_make_buffer_rsrc(p.h2, 0, 0xFFFFFFFFu, 0x00020000);
+
+    // ---- staging of the haloed, scaled, pre-split input image of a round, in two halves: (1) loads into registers,
+    // (2) block maximum -> scale, conversion, LDS.  Item = (8-channel group, image position).
+    float raw[PO_ITEMS][8];
+    auto stage_load = [&](const int rnd) {
+        const int n_ = rnd >> RPF_SHIFT;
+        const int y0_ = ((rnd & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX) >> LOGW;
+        const float* zb = p.z + (long)n_ * p.z_ns;
+        const float* cb = p.cond + (long)n_ * p.cond_ns;
+#pragma unroll
+        for (int it = 0; it < PO_ITEMS; ++it) {
+            const int item = tid + it * 64 * PO_WAVES;
+            const bool live = item < NG * IPOS;
+            const int g = live ? item / IPOS : 0, pos = live ? item - g * IPOS : 0;
+            const int iy = pos / IW, ix = pos - iy * IW;
+            const int gy = y0_ - 1 + iy, gx = ix - 1;
+            const bool ok = live && gy >= 0 && gy < W && gx >= 0 && gx < W;
+            const int off = ok ? gy * W + gx : 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int ci = 8 * g + j;
+                const int cc = ci < Cin ? ci : 0;
+                const float* src = cc < p.Ch ? zb + (long)cc * HW : cb + (long)(cc - p.Ch) * HW;
+                raw[it][j] = src[off];   // (masked in stage_finish: no use of the value here, the load stays in flight)
+            }
+        }
+    };
+    float u1_next = 0.f;   // 1 / (image scale * weight scale) of the image staged last
+    auto stage_finish = [&](const int rnd) {
+        const int y0_ = ((rnd & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX) >> LOGW;
+        float vm = 0.f;
+#pragma unroll
+        for (int it = 0; it < PO_ITEMS; ++it) {
+            const int item = tid + it * 64 * PO_WAVES;
+            const bool live = item < NG * IPOS;
+            const int g = live ? item / IPOS : 0, pos = live ? item - g * IPOS : 0;
+            const int iy = pos / IW, ix = pos - iy * IW;
+            const int gy = y0_ - 1 + iy, gx = ix - 1;
+            const bool ok = live && gy >= 0 && gy < W && gx >= 0 && gx < W;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                raw[it][j] = (ok && 8 * g + j < Cin) ? raw[it][j] : 0.f;
+                vm = fmaxf(vm, fabsf(raw[it][j]));
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) vm = fmaxf(vm, __shfl_xor(vm, off, 64));
+        if (lane == 0) red[wave] = vm;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();
+        vm = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+        const int Eimg = po_exp_of(vm);
+        const float sc_img = __uint_as_float((unsigned)(268 - Eimg) << 23);
+        u1_next = __uint_as_float((unsigned)(Eimg - 14) << 23) * inv_w1;   // undoes image and weight scale
+#pragma unroll
+        for (int it = 0; it < PO_ITEMS; ++it) {
+            const int item = tid + it * 64 * PO_WAVES;
+            if (item < NG * IPOS) {
+                const int g = item / IPOS, pos = item - g * IPOS;
+                f16x8 hi, lo;
+                po_split_f16(raw[it], sc_img, hi, lo);
+                img[(0 * NG + g) * IPOS + pos] = hi;
+                img[(1 * NG + g) * IPOS + pos] = lo;
+            }
+        }
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");   // image (and red[] reads) done before the next barrier
+    };
+
+    int round = blockIdx.x;
+    if (round < p.n_rounds) {
+        const bool more = true;
+        (void)more;
+        dma(po_group_base(NG, NP, 0), po_group_size(NG, NP, 0), 0);
+        dma(po_group_base(NG, NP, 1), po_group_size(NG, NP, 1), 1);
+        stage_load(round);
+        stage_finish(round);
+    }
+    for (; round < p.n_rounds; round += gridDim.x) {
+        const bool more = round + (int)gridDim.x < p.n_rounds;
+        const int n = round >> RPF_SHIFT;
+        const int pix0 = (round & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX;   // first pixel of the round in its frame
+        const int y0 = pix0 >> LOGW;
+        const float u1 = u1_next;
+
+        // this lane's pixel and its five tap-pair positions inside the image (lane half = tap of the pair)
+        const int pix = pix0 + 32 * wave + l31;
+        const int iy = (pix >> LOGW) - y0 + 1, ix = (pix & (W - 1)) + 1;
+        const f16x8* bp[PO_TAP_PAIRS];
+#pragma unroll
+        for (int tp = 0; tp < PO_TAP_PAIRS; ++tp) {
+            const int tA = 2 * tp, tB = 2 * tp + 1 < 9 ? 2 * tp + 1 : 4;   // the padding tap reads the centre (zero weight)
+            const int dy = kk ? (tB / 3 - 1) : (tA / 3 - 1);
+            const int dx = kk ? (tB % 3 - 1) : (tA % 3 - 1);
+            bp[tp] = img + (iy + dy) * IW + ix + dx;
+        }
+        // byte offset of (frame n, channel 4kk, this pixel) in h1 / h2 (both [N,256,H,W] with frame strides h*_ns)
+        const unsigned vo1 = (unsigned)(((long)n * p.h1_ns + (long)(4 * kk) * HW + pix) * 4);
+        const unsigned vo2 = (unsigned)(((long)n * p.h2_ns + (long)(4 * kk) * HW + pix) * 4);
+        const float* par1 = par + 4 * kk;
+        const float* par2 = par + 512 + 4 * kk;
+
+        f32x16 acc2[8];   // conv2 accumulators = h2 (all 256 channels of this lane's pixel half)
+#pragma unroll
+        for (int a2 = 0; a2 < 8; ++a2)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc2[a2][r] = 0.f;
+        int Erun = 40;    // biased exponent of this pixel's running h1 maximum (scale of what is in acc2)
+
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            if (u == 1 && more) stage_load(round + (int)gridDim.x);   // next round's image: in flight under this quad
+            // ================= conv1, output tiles 4u .. 4u+3: NG groups of 5 k-steps, four MFMA chains
+            f32x16 Q[4];
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
+#pragma unroll
+            for (int gi = 0; gi < NG; ++gi) {
+                // younger than this group's DMA: the DMA of the next group (10 / 8 instructions per wave)
+                // (+ the 8 PO_ITEMS image loads of the next round while they are in flight: quad 1, first two groups)
+                if (u == 1 && gi < 2 && more) {
+                    if (gi + 1 < NG) PO_BOUNDARY(u * (NG + 4) + gi, 10 + 8 * PO_ITEMS);
+                    else PO_BOUNDARY(u * (NG + 4) + gi, 8 + 8 * PO_ITEMS);
+                } else {
+                    if (gi + 1 < NG) PO_BOUNDARY(u * (NG + 4) + gi, 10);
+                    else PO_BOUNDARY(u * (NG + 4) + gi, 8);
+                }
+                const f16x8* fr = reinterpret_cast<const f16x8*>(lds + sl * SLOT) + lane;
+                f16x8 A[2][4][2], B[2][2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    A[0][t][0] = fr[(t * 2) * 64];
+                    A[0][t][1] = fr[(t * 2 + 1) * 64];
+                }
+#pragma unroll
+                for (int pl = 0; pl < 2; ++pl) B[0][pl] = bp[(5 * gi) / NG][(pl * NG + (5 * gi) % NG) * IPOS];
+#pragma unroll
+                for (int k = 0; k < 5; ++k) {
+                    const int s = 5 * gi + k, cur = k & 1, nxt = cur ^ 1;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][1], B[cur][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (k + 1 < 5) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            A[nxt][t][0] = fr[(((k + 1) * 4 + t) * 2) * 64];
+                            A[nxt][t][1] = fr[(((k + 1) * 4 + t) * 2 + 1) * 64];
+                        }
+#pragma unroll
+                        for (int pl = 0; pl < 2; ++pl) B[nxt][pl] = bp[(s + 1) / NG][(pl * NG + (s + 1) % NG) * IPOS];
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][0], B[cur][1]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][0], B[cur][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+            // ---- epilogue of the four tiles: ActNorm + act, store h1, per-pixel maximum
+            float vmax = 0.f;
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+                po_epilogue<ACT>(Q[t], u1, par1 + 32 * (4 * u + t), rs_h1, vo1 + (unsigned)(32 * (4 * u + t)) * ch_bytes,
+                                 ch_bytes, vmax);
+            vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));   // the other lane half holds the pixel's other channels
+            const int Enew = max(Erun, po_exp_of(vmax));
+            if (u > 0 && __any(Enew != Erun)) {
+                // a larger h1 value appeared for some pixel: bring its conv2 partial sums to the new (coarser) scale
+                const int dE = Erun - Enew;   // <= 0
+                const float f = __uint_as_float((unsigned)(dE < -126 ? 0 : 127 + dE) << 23);
+#pragma unroll
+                for (int a2 = 0; a2 < 8; ++a2)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc2[a2][r] *= f;
+            }
+            Erun = Enew;
+            const float sc_h = __uint_as_float((unsigned)(268 - Erun) << 23);
+            f16x8 hq[8][2];   // the quad's 8 k-steps as B fragments (hi, lo)
+#pragma unroll
+            for (int t = 0; t < 4; ++t)
+#pragma unroll
+                for (int sp = 0; sp < 2; ++sp) {
+                    float w8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w8[j] = Q[t][8 * sp + j];
+                    po_split_f16(w8, sc_h, hq[2 * t + sp][0], hq[2 * t + sp][1]);
+                }
+
+            // ================= conv2, K-major: h1 k-steps 8u .. 8u+7 into all eight accumulators; 4 groups of 2 k-steps,
+            // each k-step in two halves of four output tiles (four MFMA chains, fragment reads one half ahead)
+#pragma unroll
+            for (int g2 = 0; g2 < 4; ++g2) {
+                // younger: next group's DMA (8; after the last one 10 = conv1 or 2 NP = conv3) and, for the first two groups,
+                // the 64 h1 stores of the quad's epilogue
+                if (g2 < 2) PO_BOUNDARY(u * (NG + 4) + NG + g2, 8 + 64);
+                else if (g2 == 2) PO_BOUNDARY(u * (NG + 4) + NG + g2, 8);
+                else if (u == 0) PO_BOUNDARY(u * (NG + 4) + NG + g2, 10);
+                else PO_BOUNDARY(u * (NG + 4) + NG + g2, 2 * NP);
+                const f16x8* fr = reinterpret_cast<const f16x8*>(lds + sl * SLOT) + lane;
+                f16x8 A[2][4][2];
+#pragma unroll
+                for (int t = 0; t < 4; ++t) {
+                    A[0][t][0] = fr[(t * 2) * 64];
+                    A[0][t][1] = fr[(t * 2 + 1) * 64];
+                }
+#pragma unroll
+                for (int hstep = 0; hstep < 4; ++hstep) {   // (k-step of the group, half)
+                    const int kq = 2 * g2 + (hstep >> 1), half = hstep & 1, cur = hstep & 1, nxt = cur ^ 1;
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) PO_MFMA(acc2[4 * half + t], A[cur][t][1], hq[kq][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (hstep + 1 < 4) {
+#pragma unroll
+                        for (int t = 0; t < 4; ++t) {
+                            A[nxt][t][0] = fr[(((hstep + 1) * 4 + t) * 2) * 64];
+                            A[nxt][t][1] = fr[(((hstep + 1) * 4 + t) * 2 + 1) * 64];
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) PO_MFMA(acc2[4 * half + t], A[cur][t][0], hq[kq][1]);
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) PO_MFMA(acc2[4 * half + t], A[cur][t][0], hq[kq][0]);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        }
+
+        // the image buffer is free (every wave passed four barriers since its last conv1 read): next round's image
+        if (more) stage_finish(round + (int)gridDim.x);
+
+        // ================= h2 = act(ActNorm(conv2)): store, per-pixel maximum over all 256 channels, conversion
+        const float u2 = __uint_as_float((unsigned)(Erun - 14) << 23) * inv_w2;
+        float vmax2 = 0.f;
+#pragma unroll
+        for (int a2 = 0; a2 < 8; ++a2)
+            po_epilogue<ACT>(acc2[a2], u2, par2 + 32 * a2, rs_h2, vo2 + (unsigned)(32 * a2) * ch_bytes, ch_bytes, vmax2);
+        vmax2 = fmaxf(vmax2, __shfl_xor(vmax2, 32, 64));
+        const int E3 = po_exp_of(vmax2);
+        const float sc3 = __uint_as_float((unsigned)(268 - E3) << 23);
+        const float u3 = __uint_as_float((unsigned)(E3 - 14) << 23) * inv_w3;
+        f16x8 h2f[16][2];
+#pragma unroll
+        for (int a2 = 0; a2 < 8; ++a2)
+#pragma unroll
+            for (int sp = 0; sp < 2; ++sp) {
+                float w8[8];
+#pragma unroll
+                for (int j = 0; j < 8; ++j) w8[j] = acc2[a2][8 * sp + j];
+                po_split_f16(w8, sc3, h2f[2 * a2 + sp][0], h2f[2 * a2 + sp][1]);
+            }
+
+        // ================= tap-expanded conv3: 4 groups of 4 k-steps, NP chains
+        f32x16 Pacc[NP];
+#pragma unroll
+        for (int jt = 0; jt < NP; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) Pacc[jt][r] = 0.f;
+#pragma unroll
+        for (int g3 = 0; g3 < 4; ++g3) {
+            // younger: next group's DMA (2 NP; after the last one the next round's first group, if any) and, for the first
+            // two groups, the 128 h2 stores
+            if (g3 < 2) PO_BOUNDARY(2 * NG + 8 + g3, 2 * NP + 128);
+            else if (g3 == 2) PO_BOUNDARY(2 * NG + 8 + g3, 2 * NP);
+            else if (more) PO_BOUNDARY(2 * NG + 8 + g3, 10);
+            else PO_BOUNDARY(2 * NG + 8 + g3, 0);
+            const f16x8* fr = reinterpret_cast<const f16x8*>(lds + sl * SLOT) + lane;
+            f16x8 A[2][NP][2];
+#pragma unroll
+            for (int jt = 0; jt < NP; ++jt) {
+                A[0][jt][0] = fr[(jt * 2) * 64];
+                A[0][jt][1] = fr[(jt * 2 + 1) * 64];
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int s = 4 * g3 + k, cur = k & 1, nxt = cur ^ 1;
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][1], h2f[s][0]);
+                __builtin_amdgcn_sched_barrier(0);
+                if (k + 1 < 4) {
+#pragma unroll
+                    for (int jt = 0; jt < NP; ++jt) {
+                        A[nxt][jt][0] = fr[(((k + 1) * NP + jt) * 2) * 64];
+                        A[nxt][jt][1] = fr[(((k + 1) * NP + jt) * 2 + 1) * 64];
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][0], h2f[s][1]);
+#pragma unroll
+                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][0], h2f[s][0]);
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        }
+        // ---- tap-expanded conv3 output
+        float* Po = p.P + (long)n * p.P_ns + pix;
+#pragma unroll
+        for (int jt = 0; jt < NP; ++jt)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int R = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (R < 9 * p.C) Po[(long)R * HW] = Pacc[jt][r] * u3;
+            }
+    }
+#undef PO_BOUNDARY
+}
+
+template <int NG, int NP, int LOGW, int ACT>
+static int launch_po_fwd_t(const POFwdParams& p, hipStream_t s) {
+    constexpr int G3 = 8 * NP;
+    constexpr int SLOTF = 40 > G3 ? 40 : G3;
+    const size_t ldsz = (size_t)3 * SLOTF * 1024 + 4096 + 64 + (size_t)2 * NG * p.IPOS * 16;
+    if (ldsz > 160 * 1024 || NG * p.IPOS > PO_ITEMS * 64 * PO_WAVES) {
+        rfn_set_error("coupling_po_fwd: %zu bytes of LDS / %d staging items", ldsz, NG * p.IPOS);
+        return -5;
+    }
+    auto kern = coupling_po_fwd_kernel<NG, NP, LOGW, ACT>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
+    const int grid = p.n_rounds < 256 ? p.n_rounds : 256;
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * PO_WAVES), ldsz, s, p);
+    return 0;
+}
+
+template <int NG, int NP, int LOGW>
+static int launch_po_fwd(const POFwdParams& p, hipStream_t s) {
+    if (p.act == 1) return launch_po_fwd_t<NG, NP, LOGW, 1>(p, s);
+    if (p.act == 2) return launch_po_fwd_t<NG, NP, LOGW, 2>(p, s);
+    return launch_po_fwd_t<NG, NP, LOGW, 0>(p, s);
+}
+
+// shapes the fused kernel takes (the host asks before choosing this path)
+extern "C" int rfn_coupling_po_supported(int N, int C, int Cc, int Hd, int H, int W) {
+    if (N <= 0 || C <= 0 || C % 2 || Cc < 0 || H <= 0 || W <= 0) return 0;
+    const POGeom g = po_geom(C / 2 + Cc, C);
+    const bool pow2 = (H & (H - 1)) == 0 && (W & (W - 1)) == 0;
+    const bool inst = H == W && ((g.NG == 3 && g.NP == 2 && W == 32) || (g.NG == 5 && g.NP == 3 && W == 16));
+    // output tensors are addressed with 32-bit byte offsets (buffer stores)
+    const bool small = (long)N * PO_HD * H * W * 4 < (1L << 32);
+    return Hd == PO_HD && pow2 && W <= PO_ROUND_PX && (H * W) % PO_ROUND_PX == 0 && inst && small;
+}
+
+/* ---- a5 (fused)  AffineCoupling.net forward  (Flow/glow_modules.py:232-238 with :119-121, :139-142): see the header
+ * of this file.  z: output of ActNorm+InvConv (channels [0, C/2) are read), cond: the condition tensor.
+ * Outputs: h1, h2 [N,256,H,W] (saved for the backward pass) and P [N, 9C, H, W] with
+ * P[tap*C + co] = Σ_c w3[co][c][tap] h2[c] -- rfn_tap_gather_f32 turns P into the Conv2dZeros output. */
+extern "C" int rfn_coupling_po_fwd(const float* z, long z_ns, const float* cond, long cond_ns, const void* wpk,
+                                   const float* n1b, const float* n1l, const float* n2b, const float* n2l, float* h1,
+                                   long h1_ns, float* h2, long h2_ns, float* P, long P_ns, int N, int C, int Cc, int H,
+                                   int W, int act, rfn_stream_t stream) {
+    RFN_CHECK_ARG(z && wpk && n1b && n1l && n2b && n2l && h1 && h2 && P && (Cc == 0 || cond), -1);
+    RFN_CHECK_ARG(rfn_coupling_po_supported(N, C, Cc, PO_HD, H, W), -2);
+    RFN_CHECK_ARG(((uintptr_t)wpk & 15) == 0, -3);
+    RFN_CHECK_ARG(h1_ns * 4L * N < (1L << 32) && h2_ns * 4L * N < (1L << 32), -4);
+    POFwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.z = z; p.z_ns = z_ns; p.cond = cond ? cond : z; p.cond_ns = cond_ns;
+    p.wpk = reinterpret_cast<const unsigned char*>(wpk);
+    p.n1b = n1b; p.n1l = n1l; p.n2b = n2b; p.n2l = n2l;
+    p.h1 = h1; p.h1_ns = h1_ns; p.h2 = h2; p.h2_ns = h2_ns; p.P = P; p.P_ns = P_ns;
+    p.Ch = C / 2; p.Cc = Cc; p.C = C; p.N = N; p.H = H; p.W = W; p.logW = ilog2(W); p.act = act;
+    p.rpf_shift = ilog2(H * W / PO_ROUND_PX);
+    p.n_rounds = (int)((long)N * H * W / PO_ROUND_PX);
+    p.IW = W + 2;
+    p.IPOS = (PO_ROUND_PX / W + 2) * (W + 2);
+    const POGeom g = po_geom(p.Ch + Cc, C);
+    int rc = -4;
+    if (g.NG == 3 && g.NP == 2 && W == 32) rc = launch_po_fwd<3, 2, 5>(p, (hipStream_t)stream);
+    if (g.NG == 5 && g.NP == 3 && W == 16) rc = launch_po_fwd<5, 3, 4>(p, (hipStream_t)stream);
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}

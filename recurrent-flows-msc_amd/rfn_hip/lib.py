@@ -37,6 +37,11 @@ SIGNATURES = {
     "rfn_conv2d_dgrad_act_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_i, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,
                                     _c_i, _c_i, _c_s],
     "rfn_pack_conv_weights_batched_bf16x3": [_c_f, _c_i, _c_s],
+    "rfn_coupling_po_supported": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
+    "rfn_coupling_po_packed_bytes": [_c_i, _c_i],
+    "rfn_coupling_po_pack": [_c_f, _c_i, _c_s],
+    "rfn_coupling_po_fwd": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l,
+                            _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_gemm_wgrad_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_s],
     "rfn_conv3x3_wgrad_implicit_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_i,
                                           _c_s],
@@ -80,7 +85,8 @@ SIGNATURES = {
                                    _c_l, _c_i, _c_i, _c_i, _c_s],
 }
 _RESTYPES = {"rfn_last_error": ctypes.c_char_p, "rfn_packed_weight_size": ctypes.c_long,
-             "rfn_packed_weight_size_bf16x3": ctypes.c_long, "rfn_smallmap_packed_size": ctypes.c_long}
+             "rfn_packed_weight_size_bf16x3": ctypes.c_long, "rfn_smallmap_packed_size": ctypes.c_long,
+             "rfn_coupling_po_packed_bytes": ctypes.c_long}
 
 _lib = None
 

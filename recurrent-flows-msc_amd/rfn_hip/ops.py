@@ -15,9 +15,28 @@ _l = ctypes.c_long
 
 import os
 
-# arithmetic of the MFMA convolutions (forward and data-gradient): "bf16x3" = split-precision bf16 MFMA with fp32
-# accumulation (3/16 of the fp32-MFMA cycles, ~1e-5 relative error), "f32" = v_mfma_f32_32x32x2_f32.
-CONV_PRECISION = os.environ.get("RFN_CONV_PRECISION", "bf16x3")
+# Arithmetic of the MFMA convolutions (RFN_CONV_PRECISION):
+#   "mixed"  (default) forward pass fp32-grade, gradients split precision:
+#              forward  coupling nets of the shallow levels: fused kernel, two scaled fp16 pieces per operand ("f16x3s",
+#                       22 significant bits, csrc/coupling_po.hip); every other forward convolution on a map larger than
+#                       2x2: fp32 MFMA (v_mfma_f32_32x32x2_f32); 2x2 maps (latent nets, ConvLSTM, deepest flow level):
+#                       bf16x3 -- tools/precision_study.py: bits/dim error 1.3e-5 vs 1.0e-5 all-fp32-grade, 4.9e-4 all-bf16x3
+#              backward bf16x3 (data and weight gradients)
+#   "bf16x3" every convolution on two bf16 pieces per operand, three v_mfma_f32_32x32x16_bf16 per product (16 bits)
+#   "f32"    every convolution on v_mfma_f32_32x32x2_f32
+CONV_PRECISION = os.environ.get("RFN_CONV_PRECISION", "mixed")
+
+
+def bwd_b3():
+    """gradient convolutions run split precision (bf16x3)"""
+    return CONV_PRECISION in ("bf16x3", "mixed")
+
+
+def fwd_prec(H, W):
+    """arithmetic of an (unfused) forward convolution on an H x W map: 'bf16x3' or 'f32'"""
+    if CONV_PRECISION == "mixed":
+        return "bf16x3" if H * W <= 4 else "f32"
+    return CONV_PRECISION
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
 CLAMP = {"realnvp": 0, "glow": 1, "softclamp": 2, "none": 3}
@@ -111,11 +130,12 @@ def invconv_actnorm_rev(z, bias, logs, Winv):
     return x
 
 
-def pack_weight(w, flip=False):
+def pack_weight(w, flip=False, prec=None):
     """Pack a torch-layout conv weight [Cout,Cin,k,k] for the MFMA conv kernel (flip=True: data-gradient conv).
-    One streaming kernel over the packed buffer; done per call (weights change every optimizer step)."""
+    One streaming kernel over the packed buffer; done per call (weights change every optimizer step).
+    prec: 'bf16x3' | 'f32' (default: the gradient arithmetic, which is what un-annotated callers are)."""
     Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-    b3 = CONV_PRECISION == "bf16x3"
+    b3 = (prec == "bf16x3") if prec is not None else bwd_b3()
     size = (L.load().rfn_packed_weight_size_bf16x3 if b3 else L.load().rfn_packed_weight_size)(Cout, Cin, ks)
     wpk = torch.empty(size, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
@@ -172,9 +192,70 @@ class PackPlan:
         L.call("rfn_pack_conv_weights_batched_bf16x3", L._c_f(self.table.data_ptr()), _i(len(self.items)))
 
 
+# ------------------------------------------------------------------------------------------------ fused coupling net
+def coupling_po_ok(N, C, Cc, Hd, H, W, w1, w3):
+    """shapes the fused forward kernel (csrc/coupling_po.hip) takes; both 3x3 convs must really be 3x3"""
+    if os.environ.get("RFN_COUPLING_PO") == "0" or CONV_PRECISION != "mixed":
+        return False
+    if tuple(w1.shape[2:]) != (3, 3) or tuple(w3.shape[2:]) != (3, 3):
+        return False
+    return bool(L.load().rfn_coupling_po_supported(int(N), int(C), int(Cc), int(Hd), int(H), int(W)))
+
+
+class POPackPlan:
+    """Persistent fragment-ordered weight streams of a list of coupling nets [(w1, w2, w3)] and ONE launch that
+    refreshes all of them (rfn_coupling_po_pack): weights change every optimizer step."""
+
+    def __init__(self, nets):
+        import numpy as np
+        self.nets = [tuple(n) for n in nets]
+        self.ptrs = [tuple(w.data_ptr() for w in n) for n in self.nets]
+        dev = self.nets[0][0].device
+        lib = L.load()
+        rec = np.zeros(len(self.nets), dtype=np.dtype([("w1", "<u8"), ("w2", "<u8"), ("w3", "<u8"), ("dst", "<u8"),
+                                                       ("Cin", "<i4"), ("C", "<i4")]))
+        self.bufs = []
+        for i, (w1, w2, w3) in enumerate(self.nets):
+            Cin, C = int(w1.shape[1]), int(w3.shape[0])
+            for w in (w1, w2, w3):
+                assert w.is_contiguous() and w.dtype == torch.float32
+            assert tuple(w2.shape) == (256, 256, 1, 1) and int(w1.shape[0]) == 256 and int(w3.shape[1]) == 256
+            buf = torch.empty(int(lib.rfn_coupling_po_packed_bytes(Cin, C)) // 4, device=dev, dtype=torch.float32)
+            self.bufs.append(buf)
+            rec[i] = (w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), buf.data_ptr(), Cin, C)
+        self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
+
+    def valid_for(self, nets):
+        return len(nets) == len(self.nets) and all(tuple(w.data_ptr() for w in n) == p for n, p in zip(nets, self.ptrs))
+
+    def run(self):
+        L.call("rfn_coupling_po_pack", L._c_f(self.table.data_ptr()), _i(len(self.nets)))
+
+
+def coupling_po_fwd(z, cond, wpk, n1b, n1l, n2b, n2l, C, act):
+    """h1, h2, P = fused coupling net on z[:, :C/2] | cond (rfn_coupling_po_fwd); P is the tap-expanded conv3 output."""
+    N, _, H, W = z.shape
+    Cc = 0 if cond is None else int(cond.shape[1])
+    zp, zns = L.frames(z, "z")
+    cp, cns = (None, 0) if cond is None else L.frames(cond, "cond")
+    h1 = torch.empty((N, 256, H, W), device=z.device, dtype=torch.float32)
+    h2 = torch.empty((N, 256, H, W), device=z.device, dtype=torch.float32)
+    P = torch.empty((N, 9 * C, H, W), device=z.device, dtype=torch.float32)
+    Cin = C // 2 + Cc
+    npx = float(N * H * W)
+    L.call("rfn_coupling_po_fwd", zp, _l(zns), cp, _l(cns), L.dev(wpk), L.dev(n1b), L.dev(n1l), L.dev(n2b), L.dev(n2l),
+           L.dev(h1), _l(256 * H * W), L.dev(h2), _l(256 * H * W), L.dev(P), _l(9 * C * H * W), _i(N), _i(C), _i(Cc),
+           _i(H), _i(W), _i(act),
+           meta=("conv", "coupling_po_fwd_kernel", 2.0 * npx * (9 * Cin * 256 + 256 * 256 + 9 * C * 256),
+                 "N%d %d+%d->256->256->9x%d %dx%d" % (N, C // 2, Cc, C, H, W),
+                 4.0 * npx * (Cin + 512 + 9 * C) + 4.0 * (9 * Cin * 256 + 65536 + 9 * C * 256)))
+    return h1, h2, P
+
+
 def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1=None, out2=None, cout_split=None,
-               acc1=False, acc2=False):
-    """out = epilogue(conv(cat(in1,in2))) ; see rfn_conv2d_fwd_f32."""
+               acc1=False, acc2=False, prec=None):
+    """out = epilogue(conv(cat(in1,in2))) ; see rfn_conv2d_fwd_f32.  prec: arithmetic `wpk` was packed for ('bf16x3' |
+    'f32'; default: the gradient arithmetic)."""
     N, C1, H, W = in1.shape
     C2 = 0 if in2 is None else int(in2.shape[1])
     i1p, i1ns = L.frames(in1, "in1")
@@ -185,7 +266,7 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
         out1 = torch.empty((N, cout_split, H, W), device=in1.device, dtype=torch.float32)
     o1p, o1ns = L.frames(out1, "out1")
     o2p, o2ns = (None, 0) if out2 is None else L.frames(out2, "out2")
-    b3 = CONV_PRECISION == "bf16x3"
+    b3 = (prec == "bf16x3") if prec is not None else bwd_b3()
     L.call("rfn_conv2d_fwd_bf16x3" if b3 else "rfn_conv2d_fwd_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2),
            L.dev(wpk), o1p, _l(o1ns), o2p,
            _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W), _i(ks),
@@ -306,7 +387,7 @@ def conv2d_wgrad(in1, in2, g, Cout, ks, arena=None):
     N, C1, H, W = in1.shape
     C2 = 0 if in2 is None else int(in2.shape[1])
     Cin = C1 + C2
-    if CONV_PRECISION == "bf16x3" and (H * W) % 4 == 0:
+    if bwd_b3() and (H * W) % 4 == 0:
         return conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena)
     i1p, i1ns = L.frames(in1, "in1")
     i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
@@ -330,16 +411,19 @@ def zeros_conv_uses_taps(w):
     return int(w.shape[2]) == 3 and int(w.shape[0]) <= TAP_MAX_COUT
 
 
-def zeros_conv_fwd(x, w, b, logs, wpk=None):
+def zeros_conv_fwd(x, w, b, logs, wpk=None, prec=None):
     """Conv2dZeros forward (glow_modules.py:119-121): (conv3x3(x) + b) * exp(3 logs).  Tiny Cout -> tap-expanded.
-    `wpk` (optional): pre-packed weight (mode 2 = tap-expanded when zeros_conv_uses_taps(w), else mode 0)."""
+    `wpk` (optional): pre-packed weight (mode 2 = tap-expanded when zeros_conv_uses_taps(w), else mode 0), packed for
+    `prec` (default: this map's forward arithmetic)."""
     C, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-    if not zeros_conv_uses_taps(w):
-        return conv2d_raw(x, None, wpk if wpk is not None else pack_weight(w), C, ks, 2, b, logs, 0)
     N, _, H, W = x.shape
+    if prec is None:
+        prec = fwd_prec(H, W)
+    if not zeros_conv_uses_taps(w):
+        return conv2d_raw(x, None, wpk if wpk is not None else pack_weight(w, prec=prec), C, ks, 2, b, logs, 0, prec=prec)
     if wpk is None:
-        wpk = pack_weight(w.detach().permute(2, 3, 0, 1).reshape(9 * C, Cin, 1, 1).contiguous())  # [tap*C + co][ci]
-    P = conv2d_raw(x, None, wpk, 9 * C, 1)
+        wpk = pack_weight(w.detach().permute(2, 3, 0, 1).reshape(9 * C, Cin, 1, 1).contiguous(), prec=prec)  # [tap*C + co][ci]
+    P = conv2d_raw(x, None, wpk, 9 * C, 1, prec=prec)
     o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
     L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b), L.dev(logs), L.dev(o), _i(N), _i(C), _i(H), _i(W))
     return o
@@ -347,7 +431,7 @@ def zeros_conv_fwd(x, w, b, logs, wpk=None):
 
 def zeros_conv_wgrad(x, g_pre, C, ks, arena=None):
     """weight gradient of the conv inside Conv2dZeros given g_pre = grad wrt (conv + b); same switch as the forward."""
-    if ks != 3 or C > TAP_MAX_COUT or (CONV_PRECISION == "bf16x3" and _hw(x) % 4 == 0):
+    if ks != 3 or C > TAP_MAX_COUT or (bwd_b3() and _hw(x) % 4 == 0):
         return conv2d_wgrad(x, None, g_pre, C, ks, arena)
     N, Cin, H, W = x.shape
     Gs = torch.empty((N, 9 * C, H, W), device=x.device, dtype=torch.float32)
@@ -421,7 +505,8 @@ class ConvFn(torch.autograd.Function):
         Cout, ks = int(w.shape[0]), int(w.shape[2])
         p0f = None if p0 is None else p0.detach().reshape(-1).contiguous()
         p1f = None if p1 is None else p1.detach().reshape(-1).contiguous()
-        y = conv2d_raw(in1, in2, pack_weight(w), Cout, ks, ep_mode, p0f, p1f, act)
+        fp = fwd_prec(int(in1.shape[2]), int(in1.shape[3]))
+        y = conv2d_raw(in1, in2, pack_weight(w, prec=fp), Cout, ks, ep_mode, p0f, p1f, act, prec=fp)
         ctx.save_for_backward(in1, in2, w, p1f, y)
         ctx.cfg = (ep_mode, act, None if p0 is None else p0.shape, None if p1 is None else p1.shape)
         return y
@@ -471,8 +556,9 @@ class GlowStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cond, Wm, an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift,
                 act, clamp_type, packs=None):
-        """`packs` (optional): (w1 fwd, w1 dgrad, w2 fwd, w2 dgrad, w3 fwd, w3 dgrad) packed buffers kept fresh by the
-        caller's PackPlan; without it each weight is packed on the fly."""
+        """`packs` (optional): (w1 fwd, w1 dgrad, w2 fwd, w2 dgrad, w3 fwd, w3 dgrad, fused-forward stream) packed
+        buffers kept fresh by the caller's pack plans (entries may be None: packed on the fly); the forward entries are
+        bf16x3 packs and only used where that is the forward arithmetic."""
         N, C, H, W = x.shape
         Ch = C // 2
         Hd = int(w1.shape[0])
@@ -480,25 +566,40 @@ class GlowStepFn(torch.autograd.Function):
         out = actnorm_invconv_fwd(x, f(an_bias), f(an_logs), Wm.detach())
         z1 = out[:, :Ch]
         cin2 = cond if cond.shape[1] > 0 else None
-        pk = packs if packs is not None else (None,) * 6
-        ctx.packs = packs
-        # the two deepest levels (H*W <= 16): a launch is a few thousand pixels against megabytes of weights, the
-        # 3x3 convolutions go through the dense small-map kernels
+        pk = tuple(packs) + (None,) * (7 - len(packs)) if packs is not None else (None,) * 7
+        ctx.packs = pk
         Cc_ = 0 if cin2 is None else int(cin2.shape[1])
         k33 = int(w1.shape[2]) == 3 and int(w3.shape[2]) == 3
-        dense = k33 and smallmap_conv_ok(H, W, Ch, Cc_, Hd, N)
-        dense3 = k33 and smallmap_conv_ok(H, W, Hd, 0, C, N) and not zeros_conv_uses_taps(w3)
-        if dense:
-            h1 = smallmap_conv(z1, cin2, smallmap_pack(w1, H, W, False), Hd, 1, f(n1b), f(n1l), act)
+        fp = fwd_prec(H, W)
+        if coupling_po_ok(N, C, Cc_, Hd, H, W, w1, w3) and int(w2.shape[2]) == 1:
+            # shallow levels: the whole coupling net in one kernel (csrc/coupling_po.hip), h1 / h2 written once
+            po = pk[6]
+            if po is None:
+                plan = POPackPlan([(w1.detach(), w2.detach(), w3.detach())])
+                plan.run()
+                po = plan.bufs[0]
+            h1, h2, P = coupling_po_fwd(out, cin2, po, f(n1b), f(n1l), f(n2b), f(n2l), C, act)
+            o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+            b3f, l3f = f(b3), f(l3)
+            L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b3f), L.dev(l3f), L.dev(o), _i(N), _i(C), _i(H), _i(W),
+                   meta=("shell", "tap_gather", 0.0, "N%d C%d %dx%d" % (N, C, H, W), 4.0 * N * H * W * 10 * C))
         else:
-            h1 = conv2d_raw(z1, cin2, pk[0] if pk[0] is not None else pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b),
-                            f(n1l), act)
-        h2 = conv2d_raw(h1, None, pk[2] if pk[2] is not None else pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b),
-                        f(n2l), act)
-        if dense3:
-            o = smallmap_conv(h2, None, smallmap_pack(w3, H, W, False), C, 2, f(b3), f(l3), 0)
-        else:
-            o = zeros_conv_fwd(h2, w3, f(b3), f(l3), pk[4])
+            # the two deepest levels (H*W <= 16): a launch is a few thousand pixels against megabytes of weights, the
+            # 3x3 convolutions go through the dense small-map kernels (bf16x3 arithmetic: only where that is allowed)
+            dense = k33 and smallmap_conv_ok(H, W, Ch, Cc_, Hd, N)
+            dense3 = k33 and smallmap_conv_ok(H, W, Hd, 0, C, N) and not zeros_conv_uses_taps(w3)
+            b3fwd = fp == "bf16x3"
+            if dense:
+                h1 = smallmap_conv(z1, cin2, smallmap_pack(w1, H, W, False), Hd, 1, f(n1b), f(n1l), act)
+            else:
+                h1 = conv2d_raw(z1, cin2, pk[0] if (pk[0] is not None and b3fwd) else pack_weight(w1, prec=fp), Hd,
+                                int(w1.shape[2]), 1, f(n1b), f(n1l), act, prec=fp)
+            h2 = conv2d_raw(h1, None, pk[2] if (pk[2] is not None and b3fwd) else pack_weight(w2, prec=fp), Hd,
+                            int(w2.shape[2]), 1, f(n2b), f(n2l), act, prec=fp)
+            if dense3:
+                o = smallmap_conv(h2, None, smallmap_pack(w3, H, W, False), C, 2, f(b3), f(l3), 0)
+            else:
+                o = zeros_conv_fwd(h2, w3, f(b3), f(l3), pk[4] if b3fwd else None, prec=fp)
         dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
         affine_coupling_(out, o, f(scale), f(scale_shift), dlogdet, clamp_type, False)
         ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o)
@@ -539,10 +640,10 @@ class GlowStepFn(torch.autograd.Function):
         # ---- conv3 (Conv2dZeros) bwd
         go, gb3, gl3 = conv_epilogue_bwd(o, go, f(l3), 2, 0, arena=arena)
         gw3 = zeros_conv_wgrad(h2, go, C, k3, arena)
-        pk = ctx.packs if ctx.packs is not None else (None,) * 6
+        pk = ctx.packs
         w3f = pk[5] if pk[5] is not None else pack_weight(w3, True)
         w2f = pk[3] if pk[3] is not None else pack_weight(w2, True)
-        if CONV_PRECISION == "bf16x3" and Hd % 64 == 0:
+        if bwd_b3() and Hd % 64 == 0:
             # data-gradient convs with the backward of the producer's ActNorm+activation fused into their epilogue
             gh2, gn2b, gn2l = conv2d_dgrad_act(go, w3f, h2, f(n2l), act, Hd, k3)
             gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
@@ -559,7 +660,7 @@ class GlowStepFn(torch.autograd.Function):
         has_cond = cond.shape[1] > 0
         gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
         gcond = torch.empty_like(cond) if has_cond else torch.zeros_like(cond)
-        if k1 == 3 and k3 == 3 and smallmap_conv_ok(H, W, Hd, 0, Ch + Cc, N):
+        if k1 == 3 and k3 == 3 and smallmap_conv_ok(H, W, Hd, 0, Ch + Cc, N, bwd=True):
             smallmap_conv(gh1, None, smallmap_pack(w1, H, W, True), Ch + Cc, 0, out1=gz[:, :Ch],
                           out2=gcond if has_cond else None, cout_split=Ch, acc1=True)
         else:
@@ -586,9 +687,19 @@ class GlowStepRevFn(torch.autograd.Function):
         f = lambda t: None if t is None else t.detach().reshape(-1).contiguous()
         z = x.detach().clone()
         cin2 = cond if cond.shape[1] > 0 else None
-        h1 = conv2d_raw(z[:, :Ch], cin2, pack_weight(w1), Hd, int(w1.shape[2]), 1, f(n1b), f(n1l), act)
-        h2 = conv2d_raw(h1, None, pack_weight(w2), Hd, int(w2.shape[2]), 1, f(n2b), f(n2l), act)
-        o = zeros_conv_fwd(h2, w3, f(b3), f(l3))
+        fp = fwd_prec(H, W)
+        Cc_ = 0 if cin2 is None else int(cin2.shape[1])
+        if coupling_po_ok(N, C, Cc_, Hd, H, W, w1, w3) and int(w2.shape[2]) == 1:
+            plan = POPackPlan([(w1.detach(), w2.detach(), w3.detach())])
+            plan.run()
+            _, _, P = coupling_po_fwd(z, cin2, plan.bufs[0], f(n1b), f(n1l), f(n2b), f(n2l), C, act)
+            o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+            b3f, l3f = f(b3), f(l3)
+            L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b3f), L.dev(l3f), L.dev(o), _i(N), _i(C), _i(H), _i(W))
+        else:
+            h1 = conv2d_raw(z[:, :Ch], cin2, pack_weight(w1, prec=fp), Hd, int(w1.shape[2]), 1, f(n1b), f(n1l), act, prec=fp)
+            h2 = conv2d_raw(h1, None, pack_weight(w2, prec=fp), Hd, int(w2.shape[2]), 1, f(n2b), f(n2l), act, prec=fp)
+            o = zeros_conv_fwd(h2, w3, f(b3), f(l3), prec=fp)
         dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
         affine_coupling_(z, o, f(scale), f(scale_shift), dlogdet, clamp_type, True)
         out = invconv_actnorm_rev(z, f(an_bias), f(an_logs), Winv.detach())
@@ -622,9 +733,15 @@ class GaussLogpFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------ small-map dense convs
+def smallmap_arith_ok(H, W):
+    """the dense small-map kernels compute forward AND backward in bf16x3: allowed when that is this map's forward
+    arithmetic ('bf16x3' mode; 'mixed' mode on maps of at most 2x2)"""
+    return CONV_PRECISION == "bf16x3" or (CONV_PRECISION == "mixed" and H * W <= 4)
+
+
 def smallmap_supported(conv, H, W):
     """3x3 / stride 1 / pad 1 convolution on an H x W <= 16 map whose sample rows are 16-byte friendly"""
-    return (CONV_PRECISION == "bf16x3" and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
+    return (smallmap_arith_ok(H, W) and tuple(conv.kernel_size) == (3, 3) and tuple(conv.stride) == (1, 1)
             and tuple(conv.padding) == (1, 1) and tuple(conv.dilation) == (1, 1) and conv.groups == 1
             and conv.bias is not None and H * W <= 16 and (conv.in_channels * H * W) % 8 == 0
             and (conv.out_channels * H * W) % 8 == 0)
@@ -682,13 +799,13 @@ def smallmap_dense_pair(a0, packed0, n_ch0, a1, packed1, n_ch1, bias0=None, bias
     return out0, out1
 
 
-def smallmap_conv_ok(H, W, C1, C2, Cout, N):
+def smallmap_conv_ok(H, W, C1, C2, Cout, N, bwd=False):
     """3x3 conv on a map small enough for the dense kernels (rfn_smallmap_conv_bf16x3), and few enough frames: every
     32-frame row tile streams the whole dense matrix ((C1+C2)*HW x Cout*HW, on a 4x4 map more than half structural
     zeros), so the product is only used while that stream stays L2 / Infinity-Cache sized."""
     HW = H * W
     stream = -(-N // 32) * (C1 + C2) * HW * Cout * HW
-    return (CONV_PRECISION == "bf16x3" and HW <= 16 and (C1 * HW) % 8 == 0 and ((C1 + C2) * HW) % 8 == 0
+    return ((bwd_b3() if bwd else smallmap_arith_ok(H, W)) and HW <= 16 and (C1 * HW) % 8 == 0 and ((C1 + C2) * HW) % 8 == 0
             and stream <= 32 * 1024 * 1024 and os.environ.get("RFN_SMALLMAP_GLOW") != "0")
 
 
@@ -756,8 +873,9 @@ class ConvLSTMCellFn(torch.autograd.Function):
         Hc = int(w.shape[0]) // 4
         ks = int(w.shape[2])
         HW = H * W
-        cc = conv2d_raw(x, h, pack_weight(w), 4 * Hc, ks, 3 if b is not None else 0,
-                        None if b is None else b.detach().contiguous(), None, 0)
+        fp = fwd_prec(H, W)
+        cc = conv2d_raw(x, h, pack_weight(w, prec=fp), 4 * Hc, ks, 3 if b is not None else 0,
+                        None if b is None else b.detach().contiguous(), None, 0, prec=fp)
         h_out = torch.empty((N, Hc, H, W), device=x.device, dtype=torch.float32)
         c_out = torch.empty((N, Hc, H, W), device=x.device, dtype=torch.float32)
         gates = torch.empty((N, 4 * Hc, H, W), device=x.device, dtype=torch.float32)
@@ -801,7 +919,7 @@ class ConvLSTMCellFn(torch.autograd.Function):
 def convlstm_seq_supported(w, Cx, H, W):
     """time-batched ConvLSTM path: 3x3 kernel on a small map, both weight halves dense-packable"""
     Hc = int(w.shape[0]) // 4
-    return (CONV_PRECISION == "bf16x3" and tuple(w.shape[2:]) == (3, 3) and H * W <= 16 and (Cx * H * W) % 8 == 0
+    return (smallmap_arith_ok(H, W) and tuple(w.shape[2:]) == (3, 3) and H * W <= 16 and (Cx * H * W) % 8 == 0
             and (Hc * H * W) % 8 == 0 and int(w.shape[1]) == Cx + Hc)
 
 

@@ -8,10 +8,10 @@ import torch.nn.functional as F
 pytestmark = pytest.mark.gpu
 
 
-@pytest.fixture(params=["bf16x3", "f32"], autouse=True)
+@pytest.fixture(params=["mixed", "bf16x3", "f32"], autouse=True)
 def conv_precision(request):
-    """every test runs with both MFMA arithmetics of the convolutions: the shipped split-precision bf16x3 path and the
-    plain fp32 MFMA path (RFN_CONV_PRECISION)."""
+    """every test runs with the three arithmetics of the convolutions (RFN_CONV_PRECISION): the shipped 'mixed' path
+    (forward fp32-grade: fused f16x3s kernel / fp32 MFMA, gradients bf16x3), all-bf16x3 and all-fp32-MFMA."""
     from rfn_hip import ops
     old = ops.CONV_PRECISION
     ops.CONV_PRECISION = request.param
@@ -36,7 +36,7 @@ def ctol():
     """conv tolerance factor: the split-precision (bf16x3) MFMA path carries ~1e-5 relative error per contraction
     (2^-16 per product), the fp32 MFMA path ~1e-6; thresholds below are written for fp32 and scaled by this."""
     from rfn_hip import ops
-    return 5.0 if ops.CONV_PRECISION == "bf16x3" else 1.0
+    return 1.0 if ops.CONV_PRECISION == "f32" else 5.0
 
 
 def relerr(a, b):
@@ -410,3 +410,44 @@ def test_tap_expanded_zeros_conv_fwd_wgrad(K, N, Cin, C, H, W):
     assert relerr(o, ref) < 2e-5 * ctol()
     gw = K.zeros_conv_wgrad(cu(x), cu(gpre), C, 3)
     assert relerr(gw, w.grad) < 1e-4
+
+
+@pytest.mark.parametrize("N,C,Cc,S,act", [(2, 4, 16, 32, 1), (4, 8, 32, 16, 2), (41, 4, 16, 32, 2), (3, 4, 20, 32, 1)])
+def test_coupling_po_fused_forward(K, N, C, Cc, S, act, conv_precision):
+    """the fused coupling-net forward (csrc/coupling_po.hip: conv3x3 -> ActNorm -> act -> conv1x1 -> ActNorm -> act ->
+    tap-expanded conv3x3, hidden activations handed over in registers, 3-piece split arithmetic) against plain fp32
+    torch ops on the CPU: h1, h2 and the Conv2dZeros output o = gather(P).  N=41 frames of 32x32 is 328 rounds, more
+    than one per persistent workgroup; Cc=20 leaves padded input channels in the last 8-channel group.
+    Tolerance: 2e-5 of the tensor's largest magnitude (fp32-equivalent arithmetic, different summation order)."""
+    if conv_precision != "mixed":
+        pytest.skip("the fused kernel is the forward path of the 'mixed' arithmetic")
+    g = torch.Generator().manual_seed(21)
+    Ch, Cin = C // 2, C // 2 + Cc
+    z = torch.randn(N, C, S, S, generator=g)
+    cond = torch.randn(N, Cc, S, S, generator=g)
+    w1 = torch.randn(256, Cin, 3, 3, generator=g) * 0.05
+    w2 = torch.randn(256, 256, 1, 1, generator=g) * 0.05
+    w3 = torch.randn(C, 256, 3, 3, generator=g) * 0.05
+    n1b, n1l = torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
+    n2b, n2l = torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
+    b3, l3 = torch.randn(C, generator=g) * 0.1, torch.randn(C, generator=g) * 0.1
+    actf = (lambda t: F.relu(t)) if act == 1 else (lambda t: F.leaky_relu(t, 0.2))
+    xin = torch.cat((z[:, :Ch], cond), 1)
+    h1r = actf((F.conv2d(xin.double(), w1.double(), padding=1) + n1b.double().view(1, -1, 1, 1)) * n1l.double().exp().view(1, -1, 1, 1))
+    h2r = actf((F.conv2d(h1r, w2.double()) + n2b.double().view(1, -1, 1, 1)) * n2l.double().exp().view(1, -1, 1, 1))
+    orf = (F.conv2d(h2r, w3.double(), b3.double(), padding=1)) * torch.exp(3 * l3.double()).view(1, -1, 1, 1)
+    assert K.coupling_po_ok(N, C, Cc, 256, S, S, w1, w3)
+    w1c, w2c, w3c = cu(w1), cu(w2), cu(w3)
+    plan = K.POPackPlan([(w1c, w2c, w3c)])
+    plan.run()
+    h1, h2, P = K.coupling_po_fwd(cu(z), cu(cond), plan.bufs[0], cu(n1b), cu(n1l), cu(n2b), cu(n2l), C, act)
+    o = torch.empty((N, C, S, S), device="cuda")
+    from rfn_hip import lib as L
+    import ctypes
+    b3c, l3c = cu(b3), cu(l3)  # (kept alive across the launch)
+    L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b3c), L.dev(l3c), L.dev(o), ctypes.c_int(N), ctypes.c_int(C),
+           ctypes.c_int(S), ctypes.c_int(S))
+    torch.cuda.synchronize()
+    assert relerr(h1, h1r) < 2e-5
+    assert relerr(h2, h2r) < 2e-5
+    assert relerr(o, orf) < 2e-5
