@@ -157,8 +157,10 @@ class Solver(object):
         AccumulateGrad nodes are bound to the default stream and would pull it into the capture."""
         if not torch.cuda.is_available():
             return False
-        if os.environ.get("DEBUG_CLR_GRAPH_PACKET_CAPTURE") != "0":
-            # see rfn_hip/__init__.py: replays are not trustworthy with packet capture on (memset nodes race)
+        import rfn_hip
+        if not rfn_hip.graph_capture_safe():
+            # see rfn_hip/__init__.py: replays are not trustworthy with packet capture on (memset nodes race), and the
+            # flag only counts when it was in the environment before the HIP runtime initialised
             self._graph_error = "DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 must be exported before the HIP runtime starts"
             return False
         try:
@@ -252,13 +254,17 @@ class Solver(object):
                 if max_steps and self.counter >= max_steps:
                     self.stop = True
                     break
+            self.flush_log()   # graph mode keeps the last step's scalars on the device until asked
             epoch_loss = float(np.mean(self.losses)) if self.losses else math.nan
-            if self.rank == 0:
-                self.checkpoint("rfn.pt", self.epoch_i, epoch_loss)
+            # every rank must take the same decisions (checkpoint value, early stop, plateau scheduler): rank-local
+            # losses would let learning rates diverge or leave one rank waiting in an all-reduce the others never enter
+            epoch_loss, stop_flag = rdist.all_reduce_mean_scalars(torch.tensor(epoch_loss), torch.tensor(float(self.stop)))
+            self.stop = stop_flag > 0.0
+            self.checkpoint("rfn.pt", self.epoch_i, epoch_loss)   # (collective: gathers the sharded initial states)
             stop = self.earlystopping.step(self.epoch_i, epoch_loss)
             if stop or self.stop:
                 break
-            if self.earlystopping.best_loss < self.best_loss and self.epoch_i > 50 and self.rank == 0:
+            if self.earlystopping.best_loss < self.best_loss and self.epoch_i > 50:
                 self.best_loss = self.earlystopping.best_loss
                 self.checkpoint("rfn_best_model.pt", self.epoch_i, epoch_loss)
             if self.scheduler_type == "plateau":
@@ -270,19 +276,37 @@ class Solver(object):
 
     # ---------------------------------------------------------------------------------------------- state
     def checkpoint(self, model_name, epoch, loss):
-        """same dict layout as RFN/trainer.py:277-300 (model/optimizer state, histories, counters, args)."""
+        """same dict layout as RFN/trainer.py:277-300 (model/optimizer state, histories, counters, args); `args_dict` is
+        the same Namespace as a plain dict.  Collective under data parallelism: the batch-sharded initial states are
+        gathered so that the file holds the GLOBAL batch rows (a single process can resume it); rank 0 writes."""
+        state = rdist.gather_sharded_state(self.model)
+        if self.rank != 0:
+            return
         common = {"epoch": epoch, "loss": loss, "kl_loss": self.kl_loss, "recon_loss": self.recon_loss,
                   "losses": self.losses, "bits_per_dim": self.bits, "annealing_counter": self.counter,
-                  "args": self.args}
+                  "args": self.args, "args_dict": dict(vars(self.args))}
         full = dict(common)
-        full.update({"model_state_dict": self.model.state_dict(), "optimizer_state_dict": self.optimizer.state_dict(),
+        full.update({"model_state_dict": state, "optimizer_state_dict": self.optimizer.state_dict(),
                      "plot_counter": self.plot_counter})
         torch.save(full, self.path + "model_folder/" + model_name)
         torch.save(common, self.path + "model_folder/eval_dict.pt")
 
+    @staticmethod
+    def read_checkpoint(path):
+        """load an rfn.pt written by this Solver or by the reference WITHOUT executing anything from the file: tensors,
+        containers and numbers plus the one class the layout needs (argparse.Namespace)."""
+        import argparse
+        with torch.serialization.safe_globals([argparse.Namespace]):
+            return torch.load(path, map_location="cpu", weights_only=True)
+
     def load(self, load_model):
-        self.model.load_state_dict(load_model["model_state_dict"])
-        self.optimizer.load_state_dict(load_model["optimizer_state_dict"])
+        rdist.load_sharded_state(self.model, load_model["model_state_dict"])
+        try:
+            self.optimizer.load_state_dict(load_model["optimizer_state_dict"])
+        except ValueError:
+            if self.world == 1:
+                raise
+            # (the sharded initial states have other shapes per rank than in the file: their moments restart)
         self.epoch_i += load_model["epoch"]
         loss = load_model["loss"]
         self.kl_loss, self.recon_loss = load_model["kl_loss"], load_model["recon_loss"]

@@ -538,8 +538,10 @@ class SimpleParamNet(nn.Module):
 
 class ConvLSTMLayer(nn.Module):
     """Utils/modules.py:326-393.  Parameters live in `self.conv[0]` (weight [4Hc, Cin+Hc, k, k], bias U(0,1), weights
-    xavier-normal).  The peephole tensors Wci/Wcf/Wco are created lazily as zeros like the reference does; they are
-    registered as (non-trained) parameters only so that reference CPU checkpoints, which contain them, load."""
+    xavier-normal).  The peephole tensors Wci/Wcf/Wco are identically zero in every reference run.  They
+    exist as registered (non-trained) parameters only when a checkpoint that contains them was loaded (reference CPU
+    checkpoints do, GPU ones do not); otherwise they are not materialised, so `state_dict()` has the same keys before and
+    after a forward pass and matches a reference GPU checkpoint."""
 
     def __init__(self, in_channels, hidden_channels, kernel_size, bias, dropout=0, peephole=True, norm=False):
         super().__init__()
@@ -557,10 +559,9 @@ class ConvLSTMLayer(nn.Module):
         self._pe_nonzero = None
 
     def initialize_peephole(self, height, width, device):
-        if self.peephole and not hasattr(self, "Wci"):
-            for n in ("Wci", "Wcf", "Wco"):
-                self.register_parameter(n, nn.Parameter(torch.zeros(1, self.hidden_channels, height, width,
-                                                                    device=device), requires_grad=False))
+        """the reference creates zero peephole tensors here (Utils/modules.py:385-393); zeros contribute nothing, so
+        nothing is materialised unless a checkpoint brought them (see _load_from_state_dict)"""
+        return
 
     def _load_from_state_dict(self, state_dict, prefix, *args, **kw):
         # reference CPU checkpoints carry lstm.LSTMlayer.{Wci,Wcf,Wco}; GPU ones do not (SURVEY.md §0)

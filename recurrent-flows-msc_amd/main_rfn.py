@@ -155,8 +155,8 @@ def canonical_smmnist_argv(batch_size=32, n_frames=20):
 def main(args):
     from RFN.trainer import Solver
     if args.load_model:
-        import torch
-        ckpt = torch.load("." + args.path + "model_folder/rfn.pt", weights_only=False)  # our own file
+        # rfn.pt may come from the reference (drop-in checkpoints): nothing from the file is executed
+        ckpt = Solver.read_checkpoint("." + args.path + "model_folder/rfn.pt")
         args = ckpt["args"]
         solver = Solver(args)
         solver.build()

@@ -5,8 +5,11 @@ The reference has no working multi-GPU path (its nn.DataParalle
 the contract here is "same mathematics as one process running the global batch":
   * shared parameters are broadcast from rank 0 at start and their gradients are averaged every step;
   * the batch-shaped learnable initial states (z_0, z_0x, h_0, c_0, a_0, ca_0 — RFN_new.py:69-76) are SHARDED: each
-    rank owns the rows of its local sequences, so they are never reduced;
-  * data dependent ActNorm initialisation happens on rank 0's first batch and is broadcast (`sync_buffers_and_init`);
+    rank owns the rows of its local sequences, so they are never reduced; their gradients come from a LOCAL batch mean
+    and are divided by the world size (a single process takes the mean over the global batch); checkpoints hold the
+    gathered global rows (`gather_sharded_state` / `load_sharded_state`);
+  * data dependent ActNorm initialisation happens on rank 0's first batch and is broadcast
+    (`broadcast_module_state`, called by `Solver.train_step` after the first forward);
   * gradient buckets are reduced asynchronously while backward is still running (flow parameters become ready first),
     in a few large buckets: xGMI is point-to-point, fewer / larger collectives amortise the per-link latency.
 """
@@ -27,7 +30,9 @@ class GradBucketReducer:
         self.group = group
         self.world = dist.get_world_size(group) if is_dist() else 1
         # top-level batch-shaped initial states are sharded over ranks, everything else is replicated
+        named_params = list(named_params)
         params = [(n, p) for n, p in named_params if p.requires_grad and not ("." not in n and n in sharded_names)]
+        self.sharded = [p for n, p in named_params if p.requires_grad and "." not in n and n in sharded_names]
         self.params = [p for _, p in params]
         self.names = [n for n, _ in params]
         # buckets in REVERSE registration order: backward produces gradients roughly last-layer-first
@@ -88,6 +93,9 @@ class GradBucketReducer:
         """call after backward(): flush buckets whose parameters got no gradient, wait, write averages back."""
         if self.world == 1:
             return
+        grads = [p.grad for p in self.sharded if p.grad is not None]
+        if grads:
+            torch._foreach_div_(grads, float(self.world))   # local-batch mean -> global-batch mean
         for bi, n in enumerate(self._pending):
             if n > 0:
                 self._pending[bi] = 0
@@ -128,6 +136,39 @@ def broadcast_module_state(module, src=0, group=None, sharded_names=SHARDED_PARA
                 b.copy_(t.to(torch.uint8))
             else:
                 dist.broadcast(b, src=src, group=group)
+
+
+def gather_sharded_state(module, group=None, sharded_names=SHARDED_PARAM_NAMES):
+    """state_dict of `module` with the batch-sharded initial states concatenated over ranks (rank order = row order of
+    the global batch).  Collective; every rank gets the full dict (only rank 0 writes it)."""
+    sd = module.state_dict()
+    if not is_dist():
+        return sd
+    world = dist.get_world_size(group)
+    out = {}
+    for k, v in sd.items():
+        if "." not in k and k in sharded_names:
+            parts = [torch.empty_like(v) for _ in range(world)]
+            dist.all_gather(parts, v.contiguous(), group=group)
+            out[k] = torch.cat(parts, 0)
+        else:
+            out[k] = v
+    return out
+
+
+def load_sharded_state(module, state_dict, group=None, sharded_names=SHARDED_PARAM_NAMES):
+    """load_state_dict where a batch-sharded initial state in the file holds the GLOBAL rows: each rank takes its own"""
+    if is_dist():
+        world, rank = dist.get_world_size(group), dist.get_rank(group)
+        own = dict(module.named_parameters())
+        sd = {}
+        for k, v in state_dict.items():
+            if "." not in k and k in sharded_names and k in own and v.shape[0] == own[k].shape[0] * world:
+                b = own[k].shape[0]
+                v = v[rank * b:(rank + 1) * b]
+            sd[k] = v
+        state_dict = sd
+    module.load_state_dict(state_dict)
 
 
 def all_reduce_mean_scalars(*vals, group=None):

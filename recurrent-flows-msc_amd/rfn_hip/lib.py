@@ -131,20 +131,24 @@ def call(name, *args, meta=None):
         raise RuntimeError("%s failed (code %d): %s" % (name, rc, lib.rfn_last_error().decode()))
 
 
-def dev(t, name="tensor"):
-    """Validate a device tensor for the kernels and return its pointer: fp32, on the GPU, inner dims contiguous."""
+def dev(t, name="tensor", check_contiguous=True):
+    """Validate a device tensor for the kernels and return its pointer: fp32, on the GPU, contiguous (frames() checks
+    the per-frame layout of channel-slice views itself and passes check_contiguous=False)."""
     if t is None:
         return None
     if not t.is_cuda:
         raise RuntimeError("rfn_hip kernels need device tensors; %s is on %s (no CPU fallback)" % (name, t.device))
     if t.dtype != torch.float32:
         raise RuntimeError("rfn_hip kernels are fp32; %s is %s" % (name, t.dtype))
+    if check_contiguous and not t.is_contiguous():
+        raise RuntimeError("rfn_hip kernels need dense tensors; %s has shape %s stride %s" %
+                           (name, tuple(t.shape), tuple(t.stride())))
     return ctypes.c_void_p(t.data_ptr())
 
 
 def frames(t, name="tensor"):
     """(pointer, frame stride) of an [N,C,H,W] (or [N,C,HW]) tensor whose per-frame block is dense."""
-    p = dev(t, name)
+    p = dev(t, name, check_contiguous=False)
     shape, stride = t.shape, t.stride()
     exp = 1
     for d in range(t.dim() - 1, 0, -1):

@@ -162,14 +162,25 @@ with torch.no_grad():
 ref(X).backward()
 for (n, p), (_, q) in zip(ref.named_parameters(), m.named_parameters()):
     if n == "h_0":
-        # local mean over B_local vs global mean over world*B_local: sharded rows carry world x the global-row gradient
-        torch.testing.assert_close(q.grad, p.grad[rank * B_local:(rank + 1) * B_local] * world, rtol=1e-5, atol=1e-6)
+        # sharded rows: the local-batch mean is rescaled to the global-batch mean (same as the single process)
+        torch.testing.assert_close(q.grad, p.grad[rank * B_local:(rank + 1) * B_local], rtol=1e-5, atol=1e-6)
     elif n == "unused":
         assert q.grad is None or float(q.grad.abs().sum()) == 0.0
     else:
         torch.testing.assert_close(q.grad, p.grad, rtol=1e-5, atol=1e-6)
 vals = rdist.all_reduce_mean_scalars(torch.tensor(float(rank)), torch.tensor(2.0))
 assert abs(vals[0] - (world - 1) / 2) < 1e-6 and abs(vals[1] - 2.0) < 1e-6
+# a stop decision taken by ONE rank reaches all of them (Solver.train: stop flag = mean over ranks > 0)
+stop = rdist.all_reduce_mean_scalars(torch.tensor(1.0 if rank == 1 else 0.0))[0] > 0.0
+assert stop
+# checkpoints hold the GLOBAL rows of the sharded initial states; loading gives every rank its own rows back
+full = rdist.gather_sharded_state(m)
+assert tuple(full["h_0"].shape) == (world * B_local, 3)
+assert torch.equal(full["h_0"], H)
+with torch.no_grad():
+    m.h_0.zero_()
+rdist.load_sharded_state(m, full)
+assert torch.equal(m.h_0.detach(), H[rank * B_local:(rank + 1) * B_local])
 dist.destroy_process_group()
 print("rank %d ok" % rank)
 """
@@ -185,6 +196,55 @@ def test_data_parallel_reducer_world2_gloo(tmp_path):
     for r, (p, o) in enumerate(zip(procs, outs)):
         assert p.returncode == 0, "rank %d failed:\n%s" % (r, o)
         assert "rank %d ok" % r in o
+
+
+def test_graph_capture_guard_logic():
+    """hipGraph replays are only trusted when DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 preceded HIP initialisation
+    (rfn_hip/__init__.py): started with it -> safe; set by an entry point before the runtime came up -> safe; set (or
+    still unset) when the runtime was already up at import -> refuse."""
+    import rfn_hip
+    f = rfn_hip._capture_safe
+    assert f("0", "0", True) and f("0", "0", False)
+    assert f(None, "0", False)
+    assert not f(None, "0", True)          # an integrator touched torch.cuda first, then imported the package
+    assert not f(None, None, False) and not f("1", "1", False)
+    assert rfn_hip.graph_capture_safe() in (True, False)
+    src = open(os.path.join(ROOT, "recurrent-flows-msc_amd", "rfn_hip", "__init__.py")).read()
+    assert "setdefault" not in src         # the package must not set the flag itself
+
+
+def test_convlstm_state_dict_keys_do_not_change_after_forward_bookkeeping():
+    """the lazily 'created' peephole tensors are not registered, so a checkpoint written after training loads into a model
+    that has not run yet (and into the reference's GPU model); reference CPU checkpoints that carry them still load."""
+    from Utils import ConvLSTM
+    m = ConvLSTM(in_channels=4, hidden_channels=3, kernel_size=[3, 3], bias=True)
+    keys0 = set(m.state_dict())
+    m.LSTMlayer._peephole_tensors(2, 2, torch.device("cpu"))
+    assert set(m.state_dict()) == keys0
+    sd = dict(m.state_dict())
+    for n in ("Wci", "Wcf", "Wco"):
+        sd["LSTMlayer." + n] = torch.zeros(1, 3, 2, 2)
+    m2 = ConvLSTM(in_channels=4, hidden_channels=3, kernel_size=[3, 3], bias=True)
+    m2.load_state_dict(sd, strict=True)
+    assert "LSTMlayer.Wci" in m2.state_dict()
+
+
+def test_checkpoint_file_is_read_without_executing_it(tmp_path):
+    """Solver.read_checkpoint: weights_only load with argparse.Namespace as the only allow-listed class"""
+    from argparse import Namespace
+    from RFN.trainer import Solver
+    f = tmp_path / "rfn.pt"
+    torch.save({"epoch": 3, "loss": 1.5, "args": Namespace(K=2, x_dim=[1, 1, 8, 8], structure=[[4, "pool", 8]]),
+                "model_state_dict": {"w": torch.ones(2)}, "losses": [1.0, 2.0]}, f)
+    ck = Solver.read_checkpoint(str(f))
+    assert ck["args"].K == 2 and ck["args"].structure == [[4, "pool", 8]] and ck["epoch"] == 3
+
+    class Evil:
+        def __reduce__(self):
+            return (os.system, ("true",))
+    torch.save({"args": Evil()}, f)
+    with pytest.raises(Exception):
+        Solver.read_checkpoint(str(f))
 
 
 def test_per_step_batchnorm_equals_sequential_calls():
