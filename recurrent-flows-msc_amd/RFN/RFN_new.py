@@ -322,3 +322,133 @@ class RFN(nn.Module):
                 zprev, hprev, cprev = zt, ht, ct
                 condition_list = self.extractor(sample)
         return samples
+
+    # ------------------------------------------------------------------------------------------------ analyses
+    # The evaluation-time methods of the reference (RFN/RFN_new.py:496-788), built on the same kernels.  They run under
+    # torch.no_grad() like the reference's evaluator does; `draws` (optional) pins the noise in the reference's draw
+    # order so that parity tests can feed the GPU path, the oracle and the reference the same numbers.
+    def _post_prior_step(self, i, store_ht, store_at, feats, zprev, zxprev, take):
+        """one latent step (RFN_new.py:548-566 and its copies): (zt, zxt, prior_mean, prior_std, enc_mean, enc_std)"""
+        ht = store_ht[i - 1]
+        if self.enable_smoothing:
+            enc_mean, enc_std = self.encoder(torch.cat((store_at[i - 1], zxprev), dim=1))
+        else:
+            enc_mean, enc_std = self.encoder(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
+        if self.res_q:
+            prior_mean, prior_std = self.prior(torch.cat((ht, zxprev), dim=1))
+            enc_mean = prior_mean + enc_mean
+        else:
+            prior_mean, prior_std = self.prior(torch.cat((ht, zprev), dim=1))
+        zt = prior_mean + prior_std * take(prior_mean)        # draw order: prior first, then encoder
+        zxt = enc_mean + enc_std * take(enc_mean)
+        return zt, zxt, prior_mean, prior_std, enc_mean, enc_std
+
+    @staticmethod
+    def _taker(draws, dev):
+        draws = list(draws) if draws is not None else None
+
+        def take(ref=None, uniform=False):
+            if draws is not None:
+                return draws.pop(0).to(dev)
+            if ref is None:
+                return None
+            return torch.randn(ref.shape, device=dev)
+        return take, draws
+
+    def reconstruct_elbo_gap(self, x, sample=True, draws=None):
+        """RFN/RFN_new.py:687-788 -- per-frame KL and the flow NLL under z ~ prior (index 0) and z ~ posterior (index 1),
+        plus (sample=True) reconstructions.  Returns (recons, recons_flow, averageKLDseq [T,B], averageNLLseq [2,T,B]).
+        draws: per t: prior eps, encoder eps, then per z in (prior, posterior): dequantisation noise [, with sample:
+        the Split2d eps list of g(f(x)), the base eps and the Split2d eps list of the fresh sample]."""
+        assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
+        with torch.no_grad():
+            B, T = x.shape[0], x.shape[1]
+            take, dr = self._taker(draws, x.device)
+            hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
+            feats = [self.extractor(x[:, i]) for i in range(T)]
+            store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
+            kld = torch.zeros((T, B))
+            nlls = torch.zeros((2, T, B))
+            recons = torch.zeros((2, T, *x[:, 0].shape)) if sample else 0
+            recons_flow = torch.zeros((2, T, *x[:, 0].shape)) if sample else 0
+            nsplit = self.L - 1
+            for i in range(1, T):
+                zt, zxt, pm, ps, em, es = self._post_prior_step(i, store_ht, store_at, feats, zprev, zxprev, take)
+                ht = store_ht[i - 1]
+                for count, zk in enumerate((zt, zxt)):
+                    hz = torch.cat((ht, zk), dim=1)
+                    fc = self._flow_conditions(hz, feats[i - 1])
+                    b, nll = self.flow.log_prob(x[:, i], fc, hz, 0.0, take() if dr is not None else None)
+                    nlls[count, i] = nll.cpu()
+                    if sample:
+                        e1 = [take() for _ in range(nsplit)] if dr is not None else None
+                        rf = self.flow.sample(b, fc, hz, temperature=self.temperature, eps_list=e1)
+                        eb = take() if dr is not None else None
+                        e2 = [take() for _ in range(nsplit)] if dr is not None else None
+                        rs = self.flow.sample(None, fc, hz, temperature=self.temperature, eps_base=eb, eps_list=e2)
+                        recons[count, i] = rs.cpu()
+                        recons_flow[count, i] = rf.cpu()
+                zprev, zxprev = zt, zxt
+                kld[i] = kl_normal(em, es, pm, ps).sum([1, 2, 3]).cpu()
+        return recons, recons_flow, kld, nlls
+
+    def probability_future(self, x, n_conditions, draws=None):
+        """RFN/RFN_new.py:590-685 -- NLL of the frames after n_conditions conditioning frames under the LAST conditioned
+        state, with z ~ prior (index 0) and z ~ posterior (index 1).  The reference writes frame i's value to column
+        i - n_conditions - 1 of a [B, 2, T - n_conditions - 1] tensor, i.e. frame n_conditions lands in the last column
+        and is overwritten by the last frame; that indexing is kept.  draws: per warm-up step prior eps, encoder eps;
+        then per frame and z the dequantisation noise."""
+        assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
+        with torch.no_grad():
+            B, T = x.shape[0], x.shape[1]
+            take, dr = self._taker(draws, x.device)
+            hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
+            out = torch.zeros((B, 2, T - n_conditions - 1))
+            feats = [self.extractor(x[:, i]) for i in range(n_conditions)]
+            store_ht, store_at, _, _ = self._deterministic_states(feats, n_conditions, hprev, cprev, aprev, caprev)
+            zt = zxt = None
+            for i in range(1, n_conditions):
+                zt, zxt, _, _, _, _ = self._post_prior_step(i, store_ht, store_at, feats, zprev, zxprev, take)
+                zprev, zxprev = zt, zxt
+            ht = store_ht[n_conditions - 2]
+            for i in range(n_conditions, T):
+                for count, zk in enumerate((zt, zxt)):
+                    hz = torch.cat((ht, zk), dim=1)
+                    fc = self._flow_conditions(hz, feats[n_conditions - 2])
+                    _, nll = self.flow.log_prob(x[:, i], fc, hz, 0.0, take() if dr is not None else None)
+                    out[:, count, i - n_conditions - 1] = nll.cpu()
+        return out
+
+    def param_analysis(self, x, n_predictions, n_conditions, draws=None):
+        """RFN/RFN_new.py:496-588 -- prior / posterior / flow-base parameters along the sequence and one flow sample per
+        step.  (The reference passes 1.0 in the num_samples slot of flow.sample, so the sampling temperature is the
+        default 0.8; frame 0 of `predictions` stays zero.)  draws: per step prior eps, encoder eps, base eps, the
+        Split2d eps list."""
+        assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
+        with torch.no_grad():
+            B = x.shape[0]
+            T = n_conditions + n_predictions
+            take, dr = self._taker(draws, x.device)
+            hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
+            feats = [self.extractor(x[:, i]) for i in range(T)]
+            store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
+            zs = tuple(zprev.shape[1:])
+            mu_p, std_p = torch.zeros((T - 1, B) + zs), torch.zeros((T - 1, B) + zs)
+            mu_q, std_q = torch.zeros((T - 1, B) + zs), torch.zeros((T - 1, B) + zs)
+            mu_flow, std_flow = [], []
+            predictions = torch.zeros((B, T, *x.shape[2:]))
+            nsplit = self.L - 1
+            for i in range(1, T):
+                zt, zxt, pm, ps, em, es = self._post_prior_step(i, store_ht, store_at, feats, zprev, zxprev, take)
+                mu_p[i - 1], std_p[i - 1], mu_q[i - 1], std_q[i - 1] = pm.cpu(), ps.cpu(), em.cpu(), es.cpu()
+                ht = store_ht[i - 1]
+                fc = self._flow_conditions(torch.cat((ht, zxt), dim=1), feats[i - 1])
+                base = torch.cat((ht, zt), dim=1)
+                eb = take() if dr is not None else None
+                el = [take() for _ in range(nsplit)] if dr is not None else None
+                pred, params = self.flow.sample(None, fc, base, 1.0, eval_params=True, eps_base=eb, eps_list=el)
+                mu_flow.append(params[0].cpu())
+                std_flow.append(params[1].cpu())
+                predictions[:, i] = pred.cpu()
+                zprev, zxprev = zt, zxt
+        return mu_p, std_p, mu_q, std_q, torch.stack(mu_flow), torch.stack(std_flow), predictions

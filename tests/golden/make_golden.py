@@ -407,6 +407,50 @@ def gen_rfn():
     save("rfn_loss.pt", fx)
 
 
+def gen_analysis():
+    """evaluation-time methods of RFN_new (RFN/RFN_new.py:496-788) on two small configurations, model in eval mode
+    after one training call (ActNorm init, BatchNorm running statistics) and a parameter perturbation."""
+    import Utils.modules as um
+    import Flow.glow as fg
+    um.device = torch.device("cpu")
+    fg.device = torch.device("cpu")
+    from RFN.RFN_new import RFN
+    g = torch.Generator().manual_seed(4242)
+    fx = {}
+    cfgs = {"plain": dict(), "smooth_resq_skip": dict(enable_smoothing=True, res_q=True, skip_connection_flow="with_skip"),
+            "bair_like": dict(x_dim=[2, 3, 16, 16], condition_dim=[2, 3, 16, 16], D=2, skip_connection_flow="with_skip")}
+    T = 5
+    for name, kw in cfgs.items():
+        torch.manual_seed(91)
+        args = rfn_args(**kw)
+        C = args.x_dim[1]
+        m = RFN(args)
+        m.train()
+        x = (torch.rand(args.batch_size, T, C, 16, 16, generator=g) * 255).floor() / 256 - 0.5
+        m.loss(x, 0)
+        randomize_(m, g, 0.02)
+        m.eval()
+        sd = sd_clone(m)
+        e = {"args": {k: v for k, v in vars(args).items()}, "T": T, "x": x, "sd": sd}
+        with torch.no_grad():
+            start_capture()
+            _, _, kld, nlls = m.reconstruct_elbo_gap(x, sample=False)
+            e["elbo_gap"] = {"draws": [(k, t) for k, t in stop_capture()], "kld": kld, "nlls": nlls}
+            start_capture()
+            pf = m.probability_future(x, 3)
+            e["prob_future"] = {"draws": [(k, t) for k, t in stop_capture()], "n_conditions": 3, "out": pf}
+            start_capture()
+            pa = m.param_analysis(x, 2, 3)
+            e["param_analysis"] = {"draws": [(k, t) for k, t in stop_capture()], "n_predictions": 2, "n_conditions": 3,
+                                   "out": [t.detach() for t in pa]}
+            # the training loss of the same (eval-mode) model: one more end-to-end point, C = 3 + overshooting included
+            start_capture()
+            kl_fb, kl, nll = m.loss(x, 0)
+            e["loss_eval"] = {"draws": [(k, t) for k, t in stop_capture()], "out": [float(kl_fb), float(kl), float(nll)]}
+        fx[name] = e
+    save("rfn_analysis.pt", fx)
+
+
 def gen_trainer():
     """Solver.preprocess / compute_loss (RFN/trainer.py:165-175,206-219).  `RFN.trainer` imports
     data_generators (needs torchvision) so a stub module is registered first."""
@@ -445,7 +489,7 @@ def gen_trainer():
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["modules", "glow", "convlstm", "rfn", "trainer"]
+    which = sys.argv[1:] or ["modules", "glow", "convlstm", "rfn", "analysis", "trainer"]
     for w in which:
-        {"modules": gen_modules, "glow": gen_glow, "convlstm": gen_convlstm, "rfn": gen_rfn,
+        {"modules": gen_modules, "glow": gen_glow, "convlstm": gen_convlstm, "rfn": gen_rfn, "analysis": gen_analysis,
          "trainer": gen_trainer}[w]()

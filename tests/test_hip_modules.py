@@ -756,3 +756,67 @@ def test_data_parallel_rfn_equals_single_process_global_batch(tmp_path, conv_pre
         else:
             got = d0["grads"][n]
         torch.testing.assert_close(got, ref, rtol=2e-3, atol=2e-4 * float(ref.abs().max()) + 1e-7, msg=lambda s: n + ": " + s)
+
+
+@pytest.mark.parametrize("name", ["plain", "smooth_resq_skip", "bair_like"])
+def test_rfn_analysis_methods_vs_reference(golden, name):
+    """RFN.reconstruct_elbo_gap / probability_future / param_analysis and the eval-mode loss on the GPU against the
+    reference's outputs (tests/golden/rfn_analysis.pt: same weights, captured draws).  'bair_like' = C 3, overshooting
+    D 2, skip conditions.  NLL / bits-per-dim quantities within 1e-4 relative."""
+    from RFN import RFN
+    f = golden("rfn_analysis.pt")[name]
+    args = Namespace(**f["args"])
+    m = load_sd(RFN(args), f["sd"]).eval()
+    x = cu(f["x"])
+    e = f["elbo_gap"]
+    _, _, kld, nlls = m.reconstruct_elbo_gap(x, sample=False, draws=[t for _, t in e["draws"]])
+    close(kld, e["kld"], 1e-4, 1e-5)
+    close(nlls, e["nlls"], 1e-4, 1e-4)
+    e = f["prob_future"]
+    out = m.probability_future(x, e["n_conditions"], draws=[t for _, t in e["draws"]])
+    close(out, e["out"], 1e-4, 1e-4)
+    e = f["param_analysis"]
+    out = m.param_analysis(x, e["n_predictions"], e["n_conditions"], draws=[t for _, t in e["draws"]])
+    for a, b in zip(out, e["out"]):
+        close(a, b, 1e-4, 1e-5)
+    e = f["loss_eval"]
+    out = m.loss(x, 0, draws=[t for _, t in e["draws"]])
+    for a, b in zip(out, e["out"]):
+        assert abs(float(a) - b) <= 1e-4 * abs(b) + 1e-5, (float(a), b)
+    # sampling variants run and have the reference's shapes
+    rec, rec_flow, _, _ = m.reconstruct_elbo_gap(x, sample=True)
+    assert tuple(rec.shape) == (2, f["T"]) + tuple(x[:, 0].shape) and bool(torch.isfinite(rec_flow).all())
+
+
+def test_evaluator_bpd_loop(golden):
+    """Evaluator.get_loss (evaluation_metrics/error_metrics.py:370-417): the mean of per-batch bits/dim equals the
+    oracle's bits/dim of the same batches (eval mode, pinned generator), and compute_loss reproduces the reference's
+    figure of the trainer fixture."""
+    from RFN import RFN
+    from RFN.trainer import Solver
+    from evaluation_metrics import Evaluator
+    args = _tiny_solver_args("/gpurun_out/tmp/")
+    torch.manual_seed(3)
+    s = Solver(args)
+    s.device = torch.device("cuda")
+    s.model = RFN(args).cuda().train()
+    g = torch.Generator().manual_seed(8)
+    batches = [torch.rand(2, 4, 1, 16, 16, generator=g) for _ in range(3)]
+    with torch.no_grad():
+        s.model.loss(s.preprocess(batches[0].cuda()), 0)       # data dependent init
+    ev = Evaluator(s)
+    gfix = golden("trainer.pt")["compute_loss"]
+    b, k, n = ev.compute_loss(gfix["nll"], gfix["kl"], gfix["dims"], gfix["t"])
+    assert abs(b - gfix["bits"]) <= 1e-6 * abs(gfix["bits"])
+    torch.manual_seed(11)
+    mean, std = ev.get_loss("rfn.pt", 1, loader=batches)
+    assert std == -1
+    # same draws through RFN.loss directly
+    torch.manual_seed(11)
+    vals = []
+    with torch.no_grad():
+        for xb in batches:
+            xin = s.preprocess(xb.cuda())
+            _, kl, nll = s.model.loss(xin, 0)
+            vals.append(O.bits_per_dim(kl.cpu(), nll.cpu(), xin.shape[2:], xin.shape[1] - 1))
+    assert abs(float(mean) - sum(vals) / 3) <= 1e-5 * abs(sum(vals) / 3)

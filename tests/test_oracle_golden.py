@@ -259,3 +259,37 @@ def test_trainer_arithmetic(golden):
     bpd = O.bits_per_dim(g["kl"], g["nll"], g["dims"], g["t"])
     assert abs(bpd - g["bits"]) <= 1e-6 * abs(g["bits"])
     close(g["nll"] + g["beta"] * g["kl_fb"], g["loss"])
+
+
+@pytest.mark.parametrize("name", ["plain", "smooth_resq_skip", "bair_like"])
+def test_rfn_analysis_methods(golden, name):
+    """RFN.reconstruct_elbo_gap / probability_future / param_analysis (RFN/RFN_new.py:496-788) and the eval-mode loss:
+    the oracle's restatements against the reference's outputs, same weights and captured draws.  'bair_like' is the
+    C = 3 configuration with overshooting (D = 2) and skip conditions (BASELINE config 5 in miniature)."""
+    f = golden("rfn_analysis.pt")[name]
+    cfg, x = f["args"], f["x"]
+    e = f["elbo_gap"]
+    kld, nlls = O.rfn_reconstruct_elbo_gap(clone_sd(f["sd"]), cfg, x, [t for _, t in e["draws"]], False)
+    close(kld, e["kld"], 1e-4, 1e-5)
+    close(nlls, e["nlls"], 1e-4, 1e-4)
+    e = f["prob_future"]
+    out = O.rfn_probability_future(clone_sd(f["sd"]), cfg, x, e["n_conditions"], [t for _, t in e["draws"]], False)
+    close(out, e["out"], 1e-4, 1e-4)
+    e = f["param_analysis"]
+    out = O.rfn_param_analysis(clone_sd(f["sd"]), cfg, x, e["n_predictions"], e["n_conditions"], [t for _, t in e["draws"]], False)
+    for a, b in zip(out, e["out"]):
+        close(a, b, 1e-4, 1e-5)
+    e = f["loss_eval"]
+    out = O.rfn_loss(clone_sd(f["sd"]), cfg, x, [t for _, t in e["draws"]], False)
+    for a, b in zip(out, e["out"]):
+        assert abs(float(a) - b) <= 1e-4 * abs(b) + 1e-5, (float(a), b)
+
+
+def test_evaluator_bits_per_dim(golden):
+    """evaluation_metrics/error_metrics.py:358-368 is the trainer's bits/dim figure (RFN/trainer.py:214): the restatement
+    against the reference's own number in the trainer fixture (the evaluator module itself needs lpips / skimage /
+    tensorflow and cannot be imported in the build container)."""
+    g = golden("trainer.pt")["compute_loss"]
+    bpd, kl_t, nll_t = O.evaluator_compute_loss(g["nll"], g["kl"], g["dims"], g["t"])
+    assert abs(bpd - g["bits"]) <= 1e-6 * abs(g["bits"])
+    assert abs(kl_t - g["kl_loss"]) <= 1e-6 * abs(g["kl_loss"]) and abs(nll_t - g["recon_loss"]) <= 1e-6 * abs(g["recon_loss"])
