@@ -236,31 +236,35 @@ class RFN(nn.Module):
         return self.loss(x, logdet)
 
     # ------------------------------------------------------------------------------------------------ generation
-    def _posterior_rollout(self, x, n_steps, feats, sample_prior=True):
-        """shared warm-up of predict(): run the SRNN over the first n_steps frames, return final states."""
-        hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
-        store_ht, store_at, hprev, cprev = self._deterministic_states(feats, n_steps, hprev, cprev, aprev, caprev)
-        for i in range(1, n_steps):
-            ht = store_ht[i - 1]
-            if self.enable_smoothing:
-                enc_mean, enc_std = self.encoder(torch.cat((store_at[i - 1], zxprev), dim=1))
-            else:
-                enc_mean, enc_std = self.encoder(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
-            if self.res_q:
-                prior_mean, prior_std = self.prior(torch.cat((ht, zxprev), dim=1))
-                enc_mean = prior_mean + enc_mean
-            else:
-                prior_mean, prior_std = self.prior(torch.cat((ht, zprev), dim=1))
-            zprev = prior_mean + prior_std * self.kl_temperature * torch.randn_like(prior_mean)
-            zxprev = enc_mean + enc_std * torch.randn_like(enc_mean)
-        return hprev, cprev, zprev, zxprev
+    # `draws` (optional, tests): the noise in the reference's draw order, see each method.
+    def _flow_sample(self, fc, hz, take, pinned, z=None):
+        """flow.sample with pinned draws: base eps (only when z is None), then the Split2d eps list, coarsest first"""
+        eb = take() if (pinned and z is None) else None
+        el = [take() for _ in range(self.L - 1)] if pinned else None
+        return self.flow.sample(z, fc, hz, temperature=self.temperature, eps_base=eb, eps_list=el)
 
-    def predict(self, x, n_predictions, n_conditions):
-        """RFN/RFN_new.py:256-360 — condition on n_conditions frames, roll the prior forward n_predictions frames."""
+    def predict(self, x, n_predictions, n_conditions, draws=None):
+        """RFN/RFN_new.py:256-360 — condition on n_conditions frames, roll the prior forward n_predictions frames.
+        draws: per warm-up step prior eps, encoder eps; per prediction prior eps, base eps, Split2d eps list."""
         assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
         with torch.no_grad():
+            take, dr = self._taker(draws, x.device)
+            hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
             feats = [self.extractor(x[:, i]) for i in range(n_conditions)]
-            hprev, cprev, zprev, _ = self._posterior_rollout(x, n_conditions, feats)
+            store_ht, store_at, hprev, cprev = self._deterministic_states(feats, n_conditions, hprev, cprev, aprev, caprev)
+            for i in range(1, n_conditions):
+                ht = store_ht[i - 1]
+                if self.enable_smoothing:
+                    enc_mean, enc_std = self.encoder(torch.cat((store_at[i - 1], zxprev), dim=1))
+                else:
+                    enc_mean, enc_std = self.encoder(torch.cat((ht, zxprev, self._last(feats[i])), dim=1))
+                if self.res_q:
+                    prior_mean, prior_std = self.prior(torch.cat((ht, zxprev), dim=1))
+                    enc_mean = prior_mean + enc_mean
+                else:
+                    prior_mean, prior_std = self.prior(torch.cat((ht, zprev), dim=1))
+                zprev = prior_mean + prior_std * self.kl_temperature * take(prior_mean)
+                zxprev = enc_mean + enc_std * take(enc_mean)
             true_x = x[:, :n_conditions].transpose(0, 1).detach().cpu().clone()
             predictions = torch.zeros((n_predictions, *x[:, 0].shape))
             prediction = x[:, n_conditions - 1]
@@ -268,18 +272,21 @@ class RFN(nn.Module):
                 condition_list = self.extractor(prediction)
                 _, ht, ct = self.lstm(self._last(condition_list).unsqueeze(1), hprev, cprev)
                 pm, ps = self.prior(torch.cat((ht, zprev), dim=1))
-                zt = pm + ps * self.kl_temperature * torch.randn_like(pm)
+                zt = pm + ps * self.kl_temperature * take(pm)
                 hz = torch.cat((ht, zt), dim=1)
                 fc = self._flow_conditions(hz, condition_list)
-                prediction = self.flow.sample(None, fc, hz, temperature=self.temperature)
+                prediction = self._flow_sample(fc, hz, take, dr is not None)
                 predictions[i] = prediction.detach().cpu()
                 hprev, cprev, zprev = ht, ct, zt
         return true_x, predictions
 
-    def reconstruct(self, x):
-        """RFN/RFN_new.py:362-450 — posterior reconstructions and the flow bijection check g(f(x))."""
+    def reconstruct(self, x, draws=None):
+        """RFN/RFN_new.py:362-450 — posterior reconstructions and the flow bijection check g(f(x)).
+        draws: per frame encoder eps, dequantisation noise, Split2d eps list of g(f(x)), base eps + Split2d eps list of
+        the fresh sample."""
         assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
         with torch.no_grad():
+            take, dr = self._taker(draws, x.device)
             T = x.shape[1]
             hprev, cprev, aprev, caprev, _, zxprev, _, _, _ = self.get_inits()
             recons = torch.zeros((T, *x[:, 0].shape))
@@ -295,29 +302,31 @@ class RFN(nn.Module):
                 if self.res_q:
                     prior_mean, _ = self.prior(torch.cat((ht, zxprev), dim=1))
                     enc_mean = prior_mean + enc_mean
-                zxt = enc_mean + enc_std * torch.randn_like(enc_mean)
+                zxt = enc_mean + enc_std * take(enc_mean)
                 hz = torch.cat((ht, zxt), dim=1)
                 fc = self._flow_conditions(hz, feats[i - 1])
-                z, _ = self.flow.log_prob(x[:, i], fc, hz, 0.0)
-                recons_flow[i] = self.flow.sample(z, fc, hz, temperature=self.temperature).cpu()
-                recons[i] = self.flow.sample(None, fc, hz, temperature=self.temperature).cpu()
+                z, _ = self.flow.log_prob(x[:, i], fc, hz, 0.0, take() if dr is not None else None)
+                recons_flow[i] = self._flow_sample(fc, hz, take, dr is not None, z=z).cpu()
+                recons[i] = self._flow_sample(fc, hz, take, dr is not None).cpu()
                 zxprev = zxt
         return recons, recons_flow
 
-    def sample(self, x, n_samples):
-        """RFN/RFN_new.py:453-494 — unconditional roll-out from the first frame."""
+    def sample(self, x, n_samples, draws=None):
+        """RFN/RFN_new.py:453-494 — unconditional roll-out from the first frame.
+        draws: per sample prior eps, base eps, Split2d eps list."""
         assert len(x.shape) == 5, "x must be [bs, t, c, h, w]"
         with torch.no_grad():
+            take, dr = self._taker(draws, x.device)
             hprev, cprev, _, _, zprev, _, _, _, _ = self.get_inits()
             samples = torch.zeros((n_samples, *x[:, 0].shape))
             condition_list = self.extractor(x[:, 0])
             for i in range(n_samples):
                 _, ht, ct = self.lstm(self._last(condition_list).unsqueeze(1), hprev, cprev)
                 pm, ps = self.prior(torch.cat((ht, zprev), dim=1))
-                zt = pm + ps * torch.randn_like(pm)
+                zt = pm + ps * take(pm)
                 hz = torch.cat((ht, zt), dim=1)
                 fc = self._flow_conditions(hz, condition_list)
-                sample = self.flow.sample(None, fc, hz, temperature=self.temperature)
+                sample = self._flow_sample(fc, hz, take, dr is not None)
                 samples[i] = sample.cpu()
                 zprev, hprev, cprev = zt, ht, ct
                 condition_list = self.extractor(sample)

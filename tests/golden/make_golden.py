@@ -443,6 +443,16 @@ def gen_analysis():
             pa = m.param_analysis(x, 2, 3)
             e["param_analysis"] = {"draws": [(k, t) for k, t in stop_capture()], "n_predictions": 2, "n_conditions": 3,
                                    "out": [t.detach() for t in pa]}
+            start_capture()
+            tx, pr = m.predict(x, 2, 3)
+            e["predict"] = {"draws": [(k, t) for k, t in stop_capture()], "n_predictions": 2, "n_conditions": 3,
+                            "true_x": tx.detach(), "predictions": pr.detach()}
+            start_capture()
+            rc, rcf = m.reconstruct(x)
+            e["reconstruct"] = {"draws": [(k, t) for k, t in stop_capture()], "recons": rc.detach(), "recons_flow": rcf.detach()}
+            start_capture()
+            sm = m.sample(x, 3)
+            e["sample"] = {"draws": [(k, t) for k, t in stop_capture()], "n_samples": 3, "samples": sm.detach()}
             # the training loss of the same (eval-mode) model: one more end-to-end point, C = 3 + overshooting included
             start_capture()
             kl_fb, kl, nll = m.loss(x, 0)

@@ -820,3 +820,26 @@ def test_evaluator_bpd_loop(golden):
             _, kl, nll = s.model.loss(xin, 0)
             vals.append(O.bits_per_dim(kl.cpu(), nll.cpu(), xin.shape[2:], xin.shape[1] - 1))
     assert abs(float(mean) - sum(vals) / 3) <= 1e-5 * abs(sum(vals) / 3)
+
+
+@pytest.mark.parametrize("name", ["plain", "smooth_resq_skip", "bair_like"])
+def test_rfn_generation_methods_vs_reference(golden, name):
+    """RFN.predict / reconstruct / sample on the GPU (reverse Glow steps through the fused kernel where it applies)
+    against the reference's outputs with the captured draws.  Autoregressive: a frame feeds the next one, tolerance 1e-4
+    of the image range."""
+    from RFN import RFN
+    f = golden("rfn_analysis.pt")[name]
+    args = Namespace(**f["args"])
+    m = load_sd(RFN(args), f["sd"]).eval()
+    x = cu(f["x"])
+    e = f["predict"]
+    tx, pr = m.predict(x, e["n_predictions"], e["n_conditions"], draws=[t for _, t in e["draws"]])
+    assert torch.equal(tx, e["true_x"])
+    close(pr, e["predictions"], 1e-4, 1e-5)
+    e = f["reconstruct"]
+    rc, rcf = m.reconstruct(x, draws=[t for _, t in e["draws"]])
+    close(rc, e["recons"], 1e-4, 1e-5)
+    close(rcf, e["recons_flow"], 1e-4, 1e-5)
+    e = f["sample"]
+    sm = m.sample(x, e["n_samples"], draws=[t for _, t in e["draws"]])
+    close(sm, e["samples"], 1e-4, 1e-5)

@@ -293,3 +293,22 @@ def test_evaluator_bits_per_dim(golden):
     bpd, kl_t, nll_t = O.evaluator_compute_loss(g["nll"], g["kl"], g["dims"], g["t"])
     assert abs(bpd - g["bits"]) <= 1e-6 * abs(g["bits"])
     assert abs(kl_t - g["kl_loss"]) <= 1e-6 * abs(g["kl_loss"]) and abs(nll_t - g["recon_loss"]) <= 1e-6 * abs(g["recon_loss"])
+
+
+@pytest.mark.parametrize("name", ["plain", "smooth_resq_skip", "bair_like"])
+def test_rfn_generation_methods(golden, name):
+    """RFN.predict / reconstruct / sample (RFN/RFN_new.py:256-494) restated in the oracle against the reference's
+    outputs with the captured draws (eval mode)."""
+    f = golden("rfn_analysis.pt")[name]
+    cfg, x = f["args"], f["x"]
+    e = f["predict"]
+    tx, pr = O.rfn_predict(clone_sd(f["sd"]), cfg, x, e["n_predictions"], e["n_conditions"], [t for _, t in e["draws"]])
+    assert torch.equal(tx, e["true_x"])
+    close(pr, e["predictions"], 1e-4, 1e-5)
+    e = f["reconstruct"]
+    rc, rcf = O.rfn_reconstruct(clone_sd(f["sd"]), cfg, x, [t for _, t in e["draws"]])
+    close(rc, e["recons"], 1e-4, 1e-5)
+    close(rcf, e["recons_flow"], 1e-4, 1e-5)
+    e = f["sample"]
+    sm = O.rfn_sample(clone_sd(f["sd"]), cfg, x, e["n_samples"], [t for _, t in e["draws"]])
+    close(sm, e["samples"], 1e-4, 1e-5)
