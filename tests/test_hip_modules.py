@@ -843,3 +843,34 @@ def test_rfn_generation_methods_vs_reference(golden, name):
     e = f["sample"]
     sm = m.sample(x, e["n_samples"], draws=[t for _, t in e["draws"]])
     close(sm, e["samples"], 1e-4, 1e-5)
+
+
+@pytest.mark.parametrize("C,Cc,S", [(12, 32, 32), (24, 64, 16), (48, 128, 8), (96, 256, 4)])
+def test_glowstep_bair_channel_counts(conv_precision, C, Cc, S):
+    """BASELINE config 5 (BAIR: C = 3, L = 4 -> 12 / 24 / 48 / 96 channels per level, Hd = 256, skip conditions) at the
+    full channel counts of every level: forward values and log-det against the CPU oracle, and the reverse step inverts
+    the forward one (x -> y -> x, log-dets cancel).  Tolerances: 1e-4 of the tensor's range (forward), 2e-4 round trip."""
+    from Flow import GlowStep
+    from tests.golden_args import GLOW_DEFAULTS
+    a = dict(GLOW_DEFAULTS)
+    a["n_units_affine"] = 256
+    N = 4
+    torch.manual_seed(31)
+    gs = GlowStep([N, C, S, S], [N, Cc, S, S], glow_ns(a)).cuda().train()
+    g = torch.Generator().manual_seed(32)
+    x0 = torch.randn(N, C, S, S, generator=g)
+    c0 = torch.randn(N, Cc, S, S, generator=g)
+    gs(cu(x0), cu(c0), torch.zeros(N, device="cuda"), False)  # data dependent init
+    with torch.no_grad():
+        for prm in gs.parameters():
+            prm.add_(0.03 * torch.randn(prm.shape, generator=g).cuda())
+    gs.eval()
+    with torch.no_grad():
+        y, ld = gs(cu(x0), cu(c0), torch.zeros(N, device="cuda"), False)
+        sd = {k: v.detach().cpu().clone() for k, v in gs.state_dict().items()}
+        yo, ldo = O.glowstep(sd, "", x0, c0, torch.zeros(N), False, False)
+        close(y, yo, 1e-4, 1e-5)
+        close(ld, ldo, 1e-4, 1e-4)
+        xb, ldb = gs(y, cu(c0), ld.clone(), True)
+        close(xb, x0, 2e-4, 2e-5)
+        assert float(ldb.abs().max()) <= 2e-4 * float(ld.abs().max()) + 1e-3
