@@ -115,6 +115,23 @@ def kernel_roofline(rec, steps):
             "all_mfma_kernels": {"achieved_TFLOPs_fp32_equiv": mfma_fl / (mfma_ms * 1e-3) / 1e12,
                                  "ms_per_step": mfma_ms / steps, "flops_per_step": mfma_fl / steps},
             "hip_kernel_ms_per_step": tot_ms / steps}
+    # the memory-bound shell around the convolutions (ActNorm / InvConv / coupling / epilogue-backward / gather-scatter /
+    # ConvLSTM gates / latent step ...): aggregate algorithmic bytes over aggregate launch time, against the HBM roof
+    sh = {}
+    for name, meta, e0, e1 in rec:
+        if meta and meta[0] == "shell":
+            g = sh.setdefault(meta[1], {"calls": 0, "ms": 0.0, "bytes": 0.0})
+            g["calls"] += 1
+            g["ms"] += e0.elapsed_time(e1)
+            g["bytes"] += meta[4]
+    if sh:
+        sb, sm, sc = (sum(v[k] for v in sh.values()) for k in ("bytes", "ms", "calls"))
+        roof["shell"] = {"bound": "hbm", "achieved": sb / (sm * 1e-3) / 1e9, "peak": PEAK_HBM_GBS, "unit": "GB/s",
+                         "frac": sb / (sm * 1e-3) / 1e9 / PEAK_HBM_GBS, "ms_per_step": sm / steps,
+                         "launches_per_step": sc // steps, "bytes_per_step": sb / steps,
+                         "kernels": sorted(([k, v["calls"] // steps, round(v["ms"] / steps, 3),
+                                             round(v["bytes"] / max(v["ms"], 1e-9) / 1e6, 1)] for k, v in sh.items()),
+                                           key=lambda r: -r[2])}
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same workload (FETCH_SIZE /
     # WRITE_SIZE cannot be read from inside the process); the committed summary is attached when it is for this kernel
     try:

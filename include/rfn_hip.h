@@ -132,6 +132,22 @@ int rfn_coupling_po_fwd(const float* z, long z_ns, const float* cond, long cond_
                         long h2_ns, float* P, long P_ns, int N, int C, int Cc, int H, int W, int act,
                         rfn_stream_t stream);
 
+/* ---- a5/a6 fused shell tail of GlowStep.forward (Flow/glow_modules.py:119-121 + :276-285): with P (tap-expanded
+ * Conv2dZeros output, [N,9C,H,W]) the 3x3 shift-and-add, bias and exp(3 logs) scale are applied here and the result is
+ * also written to o_out [N,C,H,W]; without P, o_in holds that result.  z [N,C,H,W] (frame stride z_ns): channels
+ * [C/2, C) <- (z2 + o[0::2]) * exp(clamp(o[1::2])); logdet[n] = sum of the clamped log-scales is WRITTEN. */
+int rfn_gather_affine_f32(const float* P, const float* o_in, long o_ns, const float* b3, const float* l3, float* o_out,
+                          float* z, long z_ns, const float* scale, const float* scale_shift, float* logdet,
+                          int clamp_type, int N, int C, int H, int W, rfn_stream_t stream);
+/* backward of the affine coupling and of the Conv2dZeros epilogue in one launch: from gout (grad of the step's output)
+ * and glogdet [N] (may be NULL) to gz (whole tensor: first half copied from gout, second half the coupling gradient) and
+ * gpre = grad at the convolution output (what the weight / data gradient of conv3 consume).  gscale, gscale_shift [C/2]
+ * (realnvp clamp only), gb3, gl3 [C] are ACCUMULATED into (caller zeroes them). */
+int rfn_affine_zeros_bwd_f32(const float* zout, long zout_ns, const float* o, long o_ns, const float* gout, long gout_ns,
+                             const float* glogdet, const float* scale, const float* scale_shift, const float* l3,
+                             float* gz, long gz_ns, float* gpre, long gpre_ns, float* gscale, float* gscale_shift,
+                             float* gb3, float* gl3, int clamp_type, int N, int C, int HW, rfn_stream_t stream);
+
 /* Split-precision weight-gradient GEMM: gw[M][Nc] += Σ_{f,p} a[f][m][p] * b[f][n][p]  (a: [F,M,HW] frame stride a_ns,
  * b: [F,Nc,HW] frame stride b_ns; HW % 4 == 0, 16-byte aligned bases).  gw is accumulated with float atomics (caller
  * zeroes it).  1x1 weight gradients use it directly (a = output grad, b = conv input); 3x3 ones first expand the

@@ -554,6 +554,159 @@ extern "C" int rfn_affine_coupling_bwd_f32(const float* zout, long zout_ns, cons
     return 0;
 }
 
+// ---- fused forward shell tail of a Glow step: (tap-expanded) Conv2dZeros output -> affine coupling -> per-frame log-det.
+// One block per frame.  With P: o[c] = (sum_tap P[tap*C + c][y+dy-1][x+dx-1] + b3[c]) * exp(3 l3[c]) is formed here (and
+// written to o_out for the backward pass); without P, o is read from o_in.  z2 <- (z2 + o[2j]) * exp(ls), ls = clamp(o[2j+1]);
+// logdet[n] = sum ls is WRITTEN (no zero-filled accumulator, no separate gather / affine launches).
+__global__ __launch_bounds__(256) void gather_affine_kernel(const float* __restrict__ P, const float* __restrict__ o_in,
+                                                            long o_ns, const float* __restrict__ b3,
+                                                            const float* __restrict__ l3, float* __restrict__ o_out,
+                                                            float* __restrict__ z, long z_ns,
+                                                            const float* __restrict__ scale,
+                                                            const float* __restrict__ scale_shift,
+                                                            float* __restrict__ logdet, int clamp_type, int C, int H,
+                                                            int W) {
+    __shared__ float sm[4];
+    const int n = blockIdx.x, Ch = C >> 1, HW = H * W;
+    float* z2 = z + n * z_ns + (long)Ch * HW;
+    const float* Pn = P ? P + (long)n * 9 * C * HW : nullptr;
+    const float* on = o_in ? o_in + n * o_ns : nullptr;
+    float* oo = o_out ? o_out + (long)n * C * HW : nullptr;
+    float acc = 0.f;
+    for (int e = threadIdx.x; e < Ch * HW; e += 256) {
+        const int j = e / HW, p = e - j * HW;
+        float shift, s;
+        if (Pn) {
+            const int y = p / W, x = p - y * W;
+            float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                if (yy >= 0 && yy < H && xx >= 0 && xx < W) {
+                    const float* src = Pn + ((long)t * C + 2 * j) * HW + (long)yy * W + xx;
+                    a0 += src[0];
+                    a1 += src[HW];
+                }
+            }
+            shift = (a0 + b3[2 * j]) * expf(3.f * l3[2 * j]);
+            s = (a1 + b3[2 * j + 1]) * expf(3.f * l3[2 * j + 1]);
+            oo[(long)(2 * j) * HW + p] = shift;
+            oo[(long)(2 * j + 1) * HW + p] = s;
+        } else {
+            shift = on[(long)(2 * j) * HW + p];
+            s = on[(long)(2 * j + 1) * HW + p];
+        }
+        float sc = 0.f, sh = 0.f;
+        if (clamp_type == 0) {
+            sc = scale[j];
+            sh = scale_shift[j];
+        }
+        const float ls = clamp_ls(s, clamp_type, sc, sh);
+        z2[e] = (z2[e] + shift) * expf(ls);
+        acc += ls;
+    }
+    const float tot = block_sum_256(acc, sm);
+    if (threadIdx.x == 0) logdet[n] = tot;
+}
+extern "C" int rfn_gather_affine_f32(const float* P, const float* o_in, long o_ns, const float* b3, const float* l3,
+                                     float* o_out, float* z, long z_ns, const float* scale, const float* scale_shift,
+                                     float* logdet, int clamp_type, int N, int C, int H, int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(z && logdet && N >= 0 && C > 0 && (C % 2 == 0) && H > 0 && W > 0, -1);
+    RFN_CHECK_ARG((P && b3 && l3 && o_out && !o_in) || (!P && o_in), -2);
+    RFN_CHECK_ARG(clamp_type != 0 || (scale && scale_shift), -3);
+    if (N == 0) return 0;
+    hipLaunchKernelGGL(gather_affine_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, P, o_in, o_ns, b3, l3, o_out, z,
+                       z_ns, scale, scale_shift, logdet, clamp_type, C, H, W);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- fused backward shell head of a Glow step: affine coupling backward + Conv2dZeros epilogue backward.
+// grid (X, C/2): block (bx, j) sweeps channel pair j over a strided share of the N*HW (frame, pixel) pairs.
+//   gz[:, :C/2]      = gout[:, :C/2]                       (z1 passes through; the conv1 data gradient is added later)
+//   gz[:, C/2 + j]   = gout * exp(ls)
+//   go[2j]  = gz2 (d/dshift),  go[2j+1] = (gout * zout + glogdet[n]) * dls/ds
+//   gpre[c] = go[c] * exp(3 l3[c])                         (gradient at the conv output, what wgrad3 / dgrad3 consume)
+//   gscale, gshift (realnvp clamp), gb3[c] += sum gpre[c], gl3[c] += 3 sum go[c] * o[c]
+__global__ __launch_bounds__(256) void affine_zeros_bwd_kernel(
+    const float* __restrict__ zout, long zout_ns, const float* __restrict__ o, long o_ns,
+    const float* __restrict__ gout, long gout_ns, const float* __restrict__ glogdet, const float* __restrict__ scale,
+    const float* __restrict__ scale_shift, const float* __restrict__ l3, float* __restrict__ gz, long gz_ns,
+    float* __restrict__ gpre, long gpre_ns, float* __restrict__ gscale, float* __restrict__ gscale_shift,
+    float* __restrict__ gb3, float* __restrict__ gl3, int clamp_type, int N, int C, int HW) {
+    __shared__ float sm[4];
+    const int Ch = C >> 1, j = blockIdx.y;
+    float sc = 0.f, sh = 0.f;
+    if (clamp_type == 0) {
+        sc = scale[j];
+        sh = scale_shift[j];
+    }
+    const float e0 = expf(3.f * l3[2 * j]), e1 = expf(3.f * l3[2 * j + 1]);
+    float a_sc = 0.f, a_sh = 0.f, a_b0 = 0.f, a_b1 = 0.f, a_l0 = 0.f, a_l1 = 0.f;
+    const long total = (long)N * HW;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long n = q / HW;
+        const int p = (int)(q - n * HW);
+        const float o0 = o[n * o_ns + (long)(2 * j) * HW + p];
+        const float s = o[n * o_ns + (long)(2 * j + 1) * HW + p];
+        const float ls = clamp_ls(s, clamp_type, sc, sh);
+        const float e = expf(ls);
+        const float g = gout[n * gout_ns + (long)(Ch + j) * HW + p];
+        const float gls = g * zout[n * zout_ns + (long)(Ch + j) * HW + p] + (glogdet ? glogdet[n] : 0.f);
+        const float gzv = g * e;
+        gz[n * gz_ns + (long)j * HW + p] = gout[n * gout_ns + (long)j * HW + p];
+        gz[n * gz_ns + (long)(Ch + j) * HW + p] = gzv;
+        const float go1 = gls * clamp_ls_grad(s, clamp_type, sc);
+        const float u0 = gzv * e0, u1 = go1 * e1;
+        gpre[n * gpre_ns + (long)(2 * j) * HW + p] = u0;
+        gpre[n * gpre_ns + (long)(2 * j + 1) * HW + p] = u1;
+        a_b0 += u0;
+        a_b1 += u1;
+        a_l0 += gzv * o0;
+        a_l1 += go1 * s;
+        if (clamp_type == 0) {
+            a_sc += gls * tanhf(s);
+            a_sh += gls;
+        }
+    }
+    const float t_b0 = block_sum_256(a_b0, sm), t_b1 = block_sum_256(a_b1, sm);
+    const float t_l0 = block_sum_256(a_l0, sm), t_l1 = block_sum_256(a_l1, sm);
+    float t_sc = 0.f, t_sh = 0.f;
+    if (clamp_type == 0) {
+        t_sc = block_sum_256(a_sc, sm);
+        t_sh = block_sum_256(a_sh, sm);
+    }
+    if (threadIdx.x == 0) {
+        atomicAdd(&gb3[2 * j], t_b0);
+        atomicAdd(&gb3[2 * j + 1], t_b1);
+        atomicAdd(&gl3[2 * j], 3.f * t_l0);
+        atomicAdd(&gl3[2 * j + 1], 3.f * t_l1);
+        if (clamp_type == 0) {
+            atomicAdd(&gscale[j], t_sc);
+            atomicAdd(&gscale_shift[j], t_sh);
+        }
+    }
+}
+extern "C" int rfn_affine_zeros_bwd_f32(const float* zout, long zout_ns, const float* o, long o_ns, const float* gout,
+                                        long gout_ns, const float* glogdet, const float* scale, const float* scale_shift,
+                                        const float* l3, float* gz, long gz_ns, float* gpre, long gpre_ns, float* gscale,
+                                        float* gscale_shift, float* gb3, float* gl3, int clamp_type, int N, int C,
+                                        int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(zout && o && gout && l3 && gz && gpre && gb3 && gl3 && N >= 0 && C > 0 && (C % 2 == 0) && HW > 0, -1);
+    RFN_CHECK_ARG(clamp_type != 0 || (scale && scale_shift && gscale && gscale_shift), -2);
+    if (N == 0) return 0;
+    const int Ch = C / 2;
+    long tot = (long)N * HW;
+    int gx_ = (int)((tot + 255) / 256);
+    int cap = 512 / Ch < 1 ? 1 : 512 / Ch;
+    if (gx_ > cap) gx_ = cap;
+    hipLaunchKernelGGL(affine_zeros_bwd_kernel, dim3(gx_, Ch), dim3(256), 0, (hipStream_t)stream, zout, zout_ns, o, o_ns,
+                       gout, gout_ns, glogdet, scale, scale_shift, l3, gz, gz_ns, gpre, gpre_ns, gscale, gscale_shift,
+                       gb3, gl3, clamp_type, N, C, HW);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ gaussian log-prob
 #define RFN_HALF_LOG_2PI 0.91893853320467274178f
 __device__ __forceinline__ float softplusf_(float x) { return x > 20.f ? x : log1pf(expf(x)); }  // torch threshold=20

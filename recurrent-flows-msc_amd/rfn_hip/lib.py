@@ -37,6 +37,10 @@ SIGNATURES = {
     "rfn_conv2d_dgrad_act_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_i, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,
                                     _c_i, _c_i, _c_s],
     "rfn_pack_conv_weights_batched_bf16x3": [_c_f, _c_i, _c_s],
+    "rfn_gather_affine_f32": [_c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i,
+                              _c_i, _c_s],
+    "rfn_affine_zeros_bwd_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f,
+                                 _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_coupling_po_supported": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_coupling_po_packed_bytes": [_c_i, _c_i],
     "rfn_coupling_po_pack": [_c_f, _c_i, _c_s],

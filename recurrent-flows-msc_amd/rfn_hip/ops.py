@@ -55,8 +55,14 @@ def squeeze2d_raw(x, undo=False):
     else:
         y = torch.empty((N, C // 4, H * 2, W * 2), device=x.device, dtype=x.dtype)
     yp, yns = L.frames(y, "y")
-    L.call("rfn_squeeze2d_f32", xp, _l(xns), yp, _l(yns), _i(N), _i(C), _i(H), _i(W), _i(1 if undo else 0))
+    L.call("rfn_squeeze2d_f32", xp, _l(xns), yp, _l(yns), _i(N), _i(C), _i(H), _i(W), _i(1 if undo else 0),
+           meta=_shell("squeeze2d", x, 2))
     return y
+
+
+def _shell(name, t, n_tensors):
+    """profiling metadata of a memory-bound shell launch: algorithmic bytes = n_tensors x the tensor's fp32 size"""
+    return ("shell", name, 0.0, "x".join(str(int(d)) for d in t.shape), 4.0 * n_tensors * t.numel())
 
 
 def channel_stats(x):
@@ -76,7 +82,7 @@ def actnorm_invconv_fwd(x, bias, logs, Wm):
     zp, zns = L.frames(z, "z")
     bias, logs, Wm = bias.contiguous(), logs.contiguous(), Wm.contiguous()  # held until the launch is enqueued
     L.call("rfn_actnorm_invconv_fwd_f32", xp, _l(xns), L.dev(bias), L.dev(logs), L.dev(Wm), zp, _l(zns), _i(N), _i(C),
-           _i(_hw(x)))
+           _i(_hw(x)), meta=_shell("actnorm_invconv_fwd", x, 2))
     return z
 
 
@@ -114,8 +120,7 @@ def actnorm_invconv_bwd(x, bias, logs, Wm, gz, arena=None):
     gl = _zeros(arena, C, device=x.device)
     bias, logs, Wm = bias.contiguous(), logs.contiguous(), Wm.contiguous()  # held until the launch is enqueued
     L.call("rfn_actnorm_invconv_bwd_f32", xp, _l(xns), L.dev(bias), L.dev(logs), L.dev(Wm), gzp, _l(gzns), gxp, _l(gxns), L.dev(gW), L.dev(gb), L.dev(gl), _i(N), _i(C),
-           _i(_hw(x)), meta=("shell", "actnorm_invconv_bwd", 0.0, "N%d C%d HW%d" % (N, C, _hw(x)),
-                             12.0 * N * C * _hw(x)))
+           _i(_hw(x)), meta=_shell("actnorm_invconv_bwd", x, 3))
     return gx, gW, gb, gl
 
 
@@ -372,12 +377,14 @@ def conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena=None):
         i1p, i1ns = L.frames(in1, "in1")
         i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
         x9 = torch.empty((N, 9 * Cin, H, W), device=in1.device, dtype=torch.float32)
-        L.call("rfn_im2col3x3_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(x9), _i(N), _i(H), _i(W))
+        L.call("rfn_im2col3x3_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(x9), _i(N), _i(H), _i(W),
+               meta=_shell("im2col3x3", x9, 10.0 / 9.0))
         gw = gemm_wgrad(g, x9, Cout, 9 * Cin, arena)  # [co][tap*Cin + ci]
         return gw.view(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
     x = in1 if in2 is None else torch.cat((in1, in2), 1)
     gs = torch.empty((N, 9 * Cout, H, W), device=in1.device, dtype=torch.float32)
-    L.call("rfn_tap_scatter_f32", L.dev(g.contiguous()), L.dev(gs), _i(N), _i(Cout), _i(H), _i(W))
+    L.call("rfn_tap_scatter_f32", L.dev(g.contiguous()), L.dev(gs), _i(N), _i(Cout), _i(H), _i(W),
+           meta=_shell("tap_scatter", gs, 10.0 / 9.0))
     gw = gemm_wgrad(gs, x, 9 * Cout, Cin, arena)  # [tap*Cout + co][ci]
     return gw.view(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
 
@@ -400,7 +407,7 @@ def conv2d_wgrad(in1, in2, g, Cout, ks, arena=None):
     if ks == 1:
         return gwt.view(Cout, Cin, 1, 1)  # tap-major == torch layout when there is a single tap
     gw = torch.empty((Cout, Cin, ks, ks), device=in1.device, dtype=torch.float32)
-    L.call("rfn_wgrad_finish_f32", L.dev(gwt), L.dev(gw), _i(Cout), _i(Cin), _i(ks), _i(0))
+    L.call("rfn_wgrad_finish_f32", L.dev(gwt), L.dev(gw), _i(Cout), _i(Cin), _i(ks), _i(0), meta=_shell("wgrad_finish", gw, 2))
     return gw
 
 
@@ -425,7 +432,8 @@ def zeros_conv_fwd(x, w, b, logs, wpk=None, prec=None):
         wpk = pack_weight(w.detach().permute(2, 3, 0, 1).reshape(9 * C, Cin, 1, 1).contiguous(), prec=prec)  # [tap*C + co][ci]
     P = conv2d_raw(x, None, wpk, 9 * C, 1, prec=prec)
     o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
-    L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b), L.dev(logs), L.dev(o), _i(N), _i(C), _i(H), _i(W))
+    L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b), L.dev(logs), L.dev(o), _i(N), _i(C), _i(H), _i(W),
+           meta=_shell("tap_gather", P, 10.0 / 9.0))
     return o
 
 
@@ -435,7 +443,8 @@ def zeros_conv_wgrad(x, g_pre, C, ks, arena=None):
         return conv2d_wgrad(x, None, g_pre, C, ks, arena)
     N, Cin, H, W = x.shape
     Gs = torch.empty((N, 9 * C, H, W), device=x.device, dtype=torch.float32)
-    L.call("rfn_tap_scatter_f32", L.dev(g_pre.contiguous()), L.dev(Gs), _i(N), _i(C), _i(H), _i(W))
+    L.call("rfn_tap_scatter_f32", L.dev(g_pre.contiguous()), L.dev(Gs), _i(N), _i(C), _i(H), _i(W),
+           meta=_shell("tap_scatter", Gs, 10.0 / 9.0))
     gw = conv2d_wgrad(x, None, Gs, 9 * C, 1, arena)  # [9C, Cin, 1, 1]
     return gw.view(3, 3, C, Cin).permute(2, 3, 0, 1).contiguous()
 
@@ -448,7 +457,7 @@ def conv_epilogue_bwd(y, gy, logs, ep_mode, act, want_gl=True, arena=None):
     gb = _zeros(arena, C, device=gy.device)
     gl = _zeros(arena, C, device=gy.device) if want_gl else None
     L.call("rfn_conv_epilogue_bwd_f32", yp, _l(yns), gp, _l(gns), gp, _l(gns), L.dev(logs), L.dev(gb), L.dev(gl),
-           _i(N), _i(C), _i(_hw(gy)), _i(ep_mode), _i(act))
+           _i(N), _i(C), _i(_hw(gy)), _i(ep_mode), _i(act), meta=_shell("conv_epilogue_bwd", gy, 3))
     return gy, gb, gl
 
 
@@ -458,7 +467,27 @@ def affine_coupling_(z, o, scale, scale_shift, logdet, clamp_type, reverse):
     zp, zns = L.frames(z, "z")
     op, ons = L.frames(o, "o")
     L.call("rfn_affine_coupling_f32", zp, _l(zns), op, _l(ons), L.dev(scale), L.dev(scale_shift), L.dev(logdet),
-           _i(clamp_type), _i(1 if reverse else 0), _i(N), _i(C), _i(_hw(z)))
+           _i(clamp_type), _i(1 if reverse else 0), _i(N), _i(C), _i(_hw(z)), meta=_shell("affine_coupling", z, 2))
+
+
+def gather_affine_(z, o, P, b3, l3, scale, scale_shift, clamp_type):
+    """fused shell tail of the forward Glow step (rfn_gather_affine_f32): with P the tap-expanded Conv2dZeros output is
+    gathered, biased and scaled here (written to a fresh o); z's second channel half is coupled in place.
+    Returns (o, dlogdet[N]) -- dlogdet is written by the kernel, not accumulated."""
+    N, C, H, W = z.shape
+    zp, zns = L.frames(z, "z")
+    dlogdet = torch.empty(N, device=z.device, dtype=torch.float32)
+    if P is not None:
+        o = torch.empty((N, C, H, W), device=z.device, dtype=torch.float32)
+        L.call("rfn_gather_affine_f32", L.dev(P), None, _l(0), L.dev(b3), L.dev(l3), L.dev(o), zp, _l(zns), L.dev(scale),
+               L.dev(scale_shift), L.dev(dlogdet), _i(clamp_type), _i(N), _i(C), _i(H), _i(W),
+               meta=_shell("gather_affine", z, 9 + 1 + 1))  # P read (9x), o written, z2 read + written (2 x 1/2)
+    else:
+        op, ons = L.frames(o, "o")
+        L.call("rfn_gather_affine_f32", None, op, _l(ons), None, None, None, zp, _l(zns), L.dev(scale),
+               L.dev(scale_shift), L.dev(dlogdet), _i(clamp_type), _i(N), _i(C), _i(H), _i(W),
+               meta=_shell("gather_affine", z, 2))
+    return o, dlogdet
 
 
 def gauss_logp(z, o, layout, std_mode):
@@ -467,7 +496,7 @@ def gauss_logp(z, o, layout, std_mode):
     op, ons = L.frames(o, "o")
     logp = torch.zeros(N, device=z.device, dtype=torch.float32)
     L.call("rfn_gauss_logp_f32", zp, _l(zns), op, _l(ons), L.dev(logp), _i(layout), _i(std_mode), _i(N), _i(Cz),
-           _i(_hw(z)))
+           _i(_hw(z)), meta=_shell("gauss_logp", z, 3))
     return logp
 
 
@@ -579,11 +608,9 @@ class GlowStepFn(torch.autograd.Function):
                 plan.run()
                 po = plan.bufs[0]
             h1, h2, P = coupling_po_fwd(out, cin2, po, f(n1b), f(n1l), f(n2b), f(n2l), C, act)
-            o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
-            b3f, l3f = f(b3), f(l3)
-            L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b3f), L.dev(l3f), L.dev(o), _i(N), _i(C), _i(H), _i(W),
-                   meta=("shell", "tap_gather", 0.0, "N%d C%d %dx%d" % (N, C, H, W), 4.0 * N * H * W * 10 * C))
+            o = None
         else:
+            P = None
             # the two deepest levels (H*W <= 16): a launch is a few thousand pixels against megabytes of weights, the
             # 3x3 convolutions go through the dense small-map kernels (bf16x3 arithmetic: only where that is allowed)
             dense = k33 and smallmap_conv_ok(H, W, Ch, Cc_, Hd, N)
@@ -600,8 +627,7 @@ class GlowStepFn(torch.autograd.Function):
                 o = smallmap_conv(h2, None, smallmap_pack(w3, H, W, False), C, 2, f(b3), f(l3), 0)
             else:
                 o = zeros_conv_fwd(h2, w3, f(b3), f(l3), pk[4] if b3fwd else None, prec=fp)
-        dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
-        affine_coupling_(out, o, f(scale), f(scale_shift), dlogdet, clamp_type, False)
+        o, dlogdet = gather_affine_(out, o, P, f(b3), f(l3), f(scale), f(scale_shift), clamp_type)
         ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o)
         ctx.cfg = (act, clamp_type)
         return out, dlogdet
@@ -622,23 +648,24 @@ class GlowStepFn(torch.autograd.Function):
         # every accumulate-into output of this node lives in one zero-filled arena (1 fill launch instead of 14)
         arena = ZeroArena(2 * Ch + 8 + 3 * 2 * (Hd + 4) + 2 * (C + 4) + k1 * k1 * Hd * (Ch + Cc) + k2 * k2 * Hd * Hd
                           + max(k3 * k3 * C * Hd, 9 * C * Hd) + C * C + 2 * C + 64, dev)
-        # ---- affine bwd: gz (z1 half = gout z1 half, z2 half computed), go
-        gz = gout.clone()
+        # ---- affine coupling bwd + Conv2dZeros epilogue bwd in one launch: gz (whole tensor) and go = grad at conv3's output
+        gz = torch.empty_like(gout)
         go = torch.empty_like(o)
         gscale = gshift = None
         if clamp_type == 0:
             gscale = arena.take(Ch)
             gshift = arena.take(Ch)
+        gb3 = arena.take(C)
+        gl3 = arena.take(C)
         op, ons = L.frames(o, "o")
         outp, outns = L.frames(out, "out")
         gop, gons = L.frames(gout, "gout")
         gzp, gzns = L.frames(gz, "gz")
         gonp, gonns = L.frames(go, "go")
-        L.call("rfn_affine_coupling_bwd_f32", outp, _l(outns), op, _l(ons), gop, _l(gons), L.dev(gdl), L.dev(f(scale)),
-               L.dev(f(scale_shift)), gzp, _l(gzns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), _i(clamp_type),
-               _i(N), _i(C), _i(HW))
-        # ---- conv3 (Conv2dZeros) bwd
-        go, gb3, gl3 = conv_epilogue_bwd(o, go, f(l3), 2, 0, arena=arena)
+        scf, shf, l3f = f(scale), f(scale_shift), f(l3)
+        L.call("rfn_affine_zeros_bwd_f32", outp, _l(outns), op, _l(ons), gop, _l(gons), L.dev(gdl), L.dev(scf),
+               L.dev(shf), L.dev(l3f), gzp, _l(gzns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), L.dev(gb3),
+               L.dev(gl3), _i(clamp_type), _i(N), _i(C), _i(HW), meta=_shell("affine_zeros_bwd", gout, 4.5))
         gw3 = zeros_conv_wgrad(h2, go, C, k3, arena)
         pk = ctx.packs
         w3f = pk[5] if pk[5] is not None else pack_weight(w3, True)
@@ -728,7 +755,7 @@ class GaussLogpFn(torch.autograd.Function):
         gzp, gzns = L.frames(gz, "gz")
         gop, gons = L.frames(go, "go")
         L.call("rfn_gauss_logp_bwd_f32", zp, _l(zns), op, _l(ons), L.dev(g.contiguous()), gzp, _l(gzns), gop, _l(gons),
-               _i(layout), _i(std_mode), _i(N), _i(Cz), _i(_hw(z)))
+               _i(layout), _i(std_mode), _i(N), _i(Cz), _i(_hw(z)), meta=_shell("gauss_logp_bwd", z, 6))
         return gz, go, None, None
 
 
@@ -846,7 +873,7 @@ class LatentStepFn(torch.autograd.Function):
         enc, pri, eps_p, eps_q = enc.contiguous(), pri.contiguous(), eps_p.contiguous(), eps_q.contiguous()
         outs = [torch.empty(shp, device=enc.device, dtype=torch.float32) for _ in range(5)]
         L.call("rfn_latent_step_fwd_f32", L.dev(enc), L.dev(pri), L.dev(eps_p), L.dev(eps_q), *[L.dev(o) for o in outs],
-               _i(B), _i(ZHW), _i(1 if res_q else 0))
+               _i(B), _i(ZHW), _i(1 if res_q else 0), meta=_shell("latent_step_fwd", enc, 5.5))
         ctx.save_for_backward(enc, pri, eps_p, eps_q)
         ctx.cfg = (B, ZHW, bool(res_q))
         return tuple(outs)
@@ -884,7 +911,7 @@ class ConvLSTMCellFn(torch.autograd.Function):
         cop, cons = L.frames(c_out, "c_out")
         pe = [None if t is None else t.detach().reshape(-1).contiguous() for t in (wci, wcf, wco)]
         L.call("rfn_convlstm_gates_fwd_f32", L.dev(cc), cp, _l(cns), L.dev(pe[0]), L.dev(pe[1]), L.dev(pe[2]), hp,
-               _l(hns), cop, _l(cons), L.dev(gates), _i(N), _i(Hc), _i(HW))
+               _l(hns), cop, _l(cons), L.dev(gates), _i(N), _i(Hc), _i(HW), meta=_shell("convlstm_gates_fwd", gates, 2.75))
         ctx.save_for_backward(x, h, c, w, gates, c_out, *[t for t in pe if t is not None])
         ctx.has_bias = b is not None
         ctx.has_pe = pe[0] is not None
@@ -907,7 +934,8 @@ class ConvLSTMCellFn(torch.autograd.Function):
         gcp, gcns = (None, 0) if gc is None else L.frames(gc.contiguous(), "gc")
         gpp, gpns = L.frames(gc_prev, "gc_prev")
         L.call("rfn_convlstm_gates_bwd_f32", L.dev(gates), cp, _l(cns), cop, _l(cons), ghp, _l(ghns), gcp, _l(gcns),
-               L.dev(pe[0]), L.dev(pe[1]), L.dev(pe[2]), L.dev(gcc), gpp, _l(gpns), _i(N), _i(Hc), _i(HW))
+               L.dev(pe[0]), L.dev(pe[1]), L.dev(pe[2]), L.dev(gcc), gpp, _l(gpns), _i(N), _i(Hc), _i(HW),
+               meta=_shell("convlstm_gates_bwd", gates, 3.25))
         gb = conv_epilogue_bwd(None, gcc, None, 3, 0, want_gl=False)[1] if ctx.has_bias else None
         gw = conv2d_wgrad(x, h, gcc, 4 * Hc, ks)
         gx = torch.empty_like(x)
@@ -948,7 +976,8 @@ class ConvLSTMSeqFn(torch.autograd.Function):
         for t in range(S):
             cc = smallmap_dense(h_prev, pk_hf, 4 * Hc, add=pre[t])
             L.call("rfn_convlstm_gates_fwd_f32", L.dev(cc), L.dev(c_prev), _l(ns), None, None, None, L.dev(h_all[t]),
-                   _l(ns), L.dev(c_all[t]), _l(ns), L.dev(gates[t]), _i(B), _i(Hc), _i(HW))
+                   _l(ns), L.dev(c_all[t]), _l(ns), L.dev(gates[t]), _i(B), _i(Hc), _i(HW),
+                   meta=_shell("convlstm_gates_fwd", gates[t], 2.75))
             h_prev, c_prev = h_all[t], c_all[t]
         ctx.save_for_backward(x_all, h0, c0, w, h_all, c_all, gates)
         ctx.has_bias = b is not None
@@ -977,7 +1006,8 @@ class ConvLSTMSeqFn(torch.autograd.Function):
             gc_prev = torch.empty_like(c0)
             L.call("rfn_convlstm_gates_bwd_f32", L.dev(gates[t]), L.dev(c_prev), _l(ns), L.dev(c_all[t]), _l(ns),
                    L.dev(gh), _l(ns if gh is not None else 0), L.dev(gc), _l(ns if gc is not None else 0), None, None, None,
-                   L.dev(gcc[t]), L.dev(gc_prev), _l(ns), _i(B), _i(Hc), _i(HW))
+                   L.dev(gcc[t]), L.dev(gc_prev), _l(ns), _i(B), _i(Hc), _i(HW),
+                   meta=_shell("convlstm_gates_bwd", gates[t], 3.25))
             gh_rec = smallmap_dense(gcc[t], pk_hb, Hc)
             gc = gc_prev
         G = gcc.view(S * B, 4 * Hc, H, W)
@@ -1004,9 +1034,10 @@ class StepBatchNormActFn(torch.autograd.Function):
         gm = None if gamma is None else gamma.detach().contiguous()
         bt = None if beta is None else beta.detach().contiguous()
         acc = torch.empty((S, C, 2), device=x.device, dtype=torch.float32)  # scratch of the split reduction
-        L.call("rfn_stepbn_stats_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(acc), _i(S), _i(B), _i(C), _i(HW))
+        L.call("rfn_stepbn_stats_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(acc), _i(S), _i(B), _i(C), _i(HW),
+               meta=_shell("stepbn_stats", x, 1))
         L.call("rfn_stepbn_apply_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(gm), L.dev(bt), L.dev(y), _i(S), _i(B),
-               _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
+               _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope), meta=_shell("stepbn_apply", x, 2))
         ctx.save_for_backward(x, mean, var, gm, bt)
         ctx.cfg = (S, B, C, HW, eps, act, slope, gamma is not None)
         ctx.mark_non_differentiable(mean, var)

@@ -40,6 +40,8 @@ def ctol():
 
 
 def relerr(a, b):
+    """max-norm relative error: max |a - b| / max |b| (accumulated fp32 sums of different order agree norm-wise, not
+    element-wise next to zero crossings); per-sample log-likelihoods are checked element-wise in test_hip_modules"""
     a, b = a.detach().cpu().double(), b.detach().cpu().double()
     return float((a - b).abs().max() / (b.abs().max() + 1e-12))
 
@@ -223,6 +225,72 @@ def test_affine_kernel_fwd_rev(K, clamp):
     K.affine_coupling_(zk, cu(o), cu(sd["scale"].reshape(-1)), cu(sd["scale_shift"].reshape(-1)), ld, K.CLAMP[clamp], True)
     assert relerr(zk, z) < 1e-5
     assert float(ld.abs().max()) < 1e-4
+
+
+@pytest.mark.parametrize("clamp", ["realnvp", "glow", "softclamp", "none"])
+@pytest.mark.parametrize("N,C,H,W", [(3, 4, 6, 6), (2, 8, 4, 4), (5, 64, 2, 2)])
+def test_fused_shell_tail_fwd_bwd(K, clamp, N, C, H, W):
+    """rfn_gather_affine_f32 / rfn_affine_zeros_bwd_f32 (the shell around conv3 of a Glow step) against autograd of the
+    oracle's Conv2dZeros epilogue + affine coupling (glow_modules.py:119-121, 276-285)."""
+    from rfn_hip import lib as L
+    import ctypes
+    g = torch.Generator().manual_seed(15)
+    Ch = C // 2
+    z = torch.randn(N, C, H, W, generator=g)
+    P = torch.randn(N, 9 * C, H, W, generator=g) * 0.3
+    b3 = torch.randn(C, generator=g) * 0.2
+    l3 = (torch.randn(C, generator=g) * 0.1).requires_grad_(True)
+    sd = {"scale": (torch.randn(Ch, 1, 1, generator=g) * 0.5).requires_grad_(True),
+          "scale_shift": (torch.randn(Ch, 1, 1, generator=g) * 0.1).requires_grad_(True)}
+    # reference: 3x3 shift-and-add of the tap-expanded output = what conv3x3 would give
+    conv = torch.zeros(N, C, H, W)
+    Pp = F.pad(P.view(N, 9, C, H, W), (1, 1, 1, 1))
+    for t in range(9):
+        conv = conv + Pp[:, t, :, t // 3:t // 3 + H, t % 3:t % 3 + W]
+    conv = conv.requires_grad_(True)
+    b3r = b3.clone().requires_grad_(True)
+    zr = z.clone().requires_grad_(True)
+    o_ref = (conv + b3r.view(1, -1, 1, 1)) * (l3.view(1, -1, 1, 1) * 3).exp()
+    shift, s_ = O.split_feature(o_ref, "cross")
+    ls = O.clamp_log_scale(sd, "", s_, clamp)
+    out_ref = torch.cat((zr[:, :Ch], (zr[:, Ch:] + shift) * ls.exp()), 1)
+    ld_ref = ls.sum(dim=[1, 2, 3])
+    sc, sh = cu(sd["scale"].detach().reshape(-1)), cu(sd["scale_shift"].detach().reshape(-1))
+    b3c, l3c = cu(b3), cu(l3.detach())
+    # forward, gathering from P
+    zk = cu(z.clone())
+    o_k, ld = K.gather_affine_(zk, None, cu(P), b3c, l3c, sc, sh, K.CLAMP[clamp])
+    assert relerr(o_k, o_ref) < 1e-5
+    assert relerr(zk, out_ref) < 1e-5
+    assert relerr(ld, ld_ref) < 1e-5
+    # forward, o given
+    zk2 = cu(z.clone())
+    o2, ld2 = K.gather_affine_(zk2, o_k, None, None, None, sc, sh, K.CLAMP[clamp])
+    assert o2 is o_k and torch.equal(zk2, zk) and torch.equal(ld2, ld)
+    # backward
+    gout = torch.randn(N, C, H, W, generator=g)
+    gld = torch.randn(N, generator=g)
+    ((out_ref * gout).sum() + (ld_ref * gld).sum()).backward()
+    goutc, gldc = cu(gout), cu(gld)
+    gz = torch.empty_like(goutc)
+    gpre = torch.empty_like(goutc)
+    acc = torch.zeros(2 * Ch + 2 * C, device="cuda")
+    gsc, gsh, gb3, gl3 = acc[:Ch], acc[Ch:2 * Ch], acc[2 * Ch:2 * Ch + C], acc[2 * Ch + C:]
+    st = C * H * W
+    rn = clamp == "realnvp"
+    L.call("rfn_affine_zeros_bwd_f32", L.dev(zk), ctypes.c_long(st), L.dev(o_k), ctypes.c_long(st), L.dev(goutc),
+           ctypes.c_long(st), L.dev(gldc), L.dev(sc), L.dev(sh), L.dev(l3c), L.dev(gz), ctypes.c_long(st), L.dev(gpre),
+           ctypes.c_long(st), L.dev(gsc, check_contiguous=False) if rn else None,
+           L.dev(gsh, check_contiguous=False) if rn else None, L.dev(gb3, check_contiguous=False),
+           L.dev(gl3, check_contiguous=False), ctypes.c_int(K.CLAMP[clamp]), ctypes.c_int(N), ctypes.c_int(C),
+           ctypes.c_int(H * W))
+    assert relerr(gz, zr.grad) < 1e-5
+    assert relerr(gpre, conv.grad) < 1e-5
+    assert relerr(gb3, b3r.grad) < 1e-4
+    assert relerr(gl3, l3.grad) < 1e-4
+    if rn:
+        assert relerr(gsc, sd["scale"].grad.reshape(-1)) < 1e-4
+        assert relerr(gsh, sd["scale_shift"].grad.reshape(-1)) < 1e-4
 
 
 @pytest.mark.parametrize("layout,std_mode", [(0, 0), (0, 1), (1, 1), (1, 0)])
