@@ -148,6 +148,24 @@ int rfn_affine_zeros_bwd_f32(const float* zout, long zout_ns, const float* o, lo
                              float* gz, long gz_ns, float* gpre, long gpre_ns, float* gscale, float* gscale_shift,
                              float* gb3, float* gl3, int clamp_type, int N, int C, int HW, rfn_stream_t stream);
 
+/* ---- a6 shell BETWEEN two consecutive Glow steps of a level, one launch each way (Flow/glow.py:31-36 unrolled over
+ * the K steps of a level).  Forward: the coupling tail of step k (as rfn_gather_affine_f32, but logdet [N] is
+ * ACCUMULATED) then, when Wm != NULL, the ActNorm + InvConv head of step k+1: znext = Wm ((z' + bias) * exp(logs)).
+ * With P == o_in == NULL only the head runs (first step of a level; z is then read only). */
+int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const float* o_in, long o_ns, const float* b3,
+                           const float* l3, float* o_out, const float* scale, const float* scale_shift, float* logdet,
+                           int clamp_type, const float* bias, const float* logs, const float* Wm, float* znext,
+                           long znext_ns, int N, int C, int H, int W, rfn_stream_t stream);
+/* Backward: rfn_actnorm_invconv_bwd_f32 of step k+1 (x = its input = step k's output, gz = gradient wrt its
+ * post-InvConv tensor; gW, gbias, glogs accumulated) whose result feeds rfn_affine_zeros_bwd_f32 of step k from
+ * registers (o .. gl3 are step k's, same meaning as there). */
+int rfn_glow_shell_bwd_f32(const float* x, long x_ns, const float* bias, const float* logs, const float* Wm,
+                           const float* gz, long gz_ns, float* gW, float* gbias, float* glogs, const float* o, long o_ns,
+                           const float* glogdet, const float* scale, const float* scale_shift, const float* l3,
+                           float* gz_prev, long gz_prev_ns, float* gpre, long gpre_ns, float* gscale,
+                           float* gscale_shift, float* gb3, float* gl3, int clamp_type, int N, int C, int HW,
+                           rfn_stream_t stream);
+
 /* Split-precision weight-gradient GEMM: gw[M][Nc] += Σ_{f,p} a[f][m][p] * b[f][n][p]  (a: [F,M,HW] frame stride a_ns,
  * b: [F,Nc,HW] frame stride b_ns; HW % 4 == 0, 16-byte aligned bases).  gw is accumulated with float atomics (caller
  * zeroes it).  1x1 weight gradients use it directly (a = output grad, b = conv input); 3x3 ones first expand the
@@ -264,7 +282,8 @@ int rfn_smallmap_dense_pair_bf16x3(const float* a0, const float* y0, float slope
                                    int N1, int B, int HW, rfn_stream_t stream);
 
 /* The same dense product behind the interface of rfn_conv2d_fwd_bf16x3 (ks = 3 implied): N frames of an H x W <= 16
- * map, two-source input, ep_mode 0-3, output channels split at cout_split, out1 optionally accumulated.  `packed` from
+ * map, two-source input, ep_mode 0-3, output channels split at cout_split; acc1 is a bit mask (1: add into out1, 2: add
+ * into out2).  `packed` from
  * rfn_smallmap_pack_bf16x3 of the [Cout][C1+C2][3][3] weight (transpose 0), or transpose 1 of the FORWARD weight for a
  * data gradient.  (C1*H*W) % 8 == 0 and ((C1+C2)*H*W) % 8 == 0.  Used for the coupling convolutions of the two deepest
  * flow levels, where a launch is a few thousand pixels against megabytes of weights. */

@@ -10,6 +10,8 @@ MI355X-first differences from the reference implementation (results are the same
   * no per-ActNorm `.item()` host syncs: initialisation state is mirrored on the host;
   * parameter-only log-det terms of all K steps of a level are summed once, not once per step.
 """
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -160,6 +162,21 @@ class ListGlow(nn.Module):
         W = torch.matmul(p, torch.matmul(L, U))
         return W, log_s.sum() * hw
 
+    @staticmethod
+    def _level_node_ok(steps, z):
+        """the one-node-per-level path: device tensors, every ActNorm of the level already initialised (the first,
+        data-initialising call walks the steps one by one), one activation / clamp for the whole level"""
+        if not z.is_cuda or os.environ.get("RFN_LEVEL_NODE") == "0":
+            return False
+        a0 = steps[0].affine
+        for s_ in steps:
+            a = s_.affine
+            if s_.norm.needs_init() or a.net[0].norm_type.needs_init() or a.net[2].norm_type.needs_init():
+                return False
+            if a.non_lin != a0.non_lin or a.clamp_type != a0.clamp_type:
+                return False
+        return True
+
     def _packed_weights(self, x_shape, condition):
         """two launches re-pack every coupling-net weight of the flow: the split-precision (bf16x3) packs of the
         data-gradient convolutions -- and of the forward convolutions where bf16x3 is the forward arithmetic -- and the
@@ -214,8 +231,23 @@ class ListGlow(nn.Module):
         for l, (squeeze, steps, split) in enumerate(self._level_steps()):
             z = squeeze(z, undo_squeeze=False)
             W, c = self._batched_invconv(steps, z.shape[2] * z.shape[3])
-            Wk = W.unbind(0) if W is not None else None  # one stack-backward instead of K select-backward + K adds
-            for k, step in enumerate(steps):
+            if W is not None and self._level_node_ok(steps, z):
+                # the K steps of the level as ONE autograd node (rfn_hip.ops.GlowLevelFn)
+                aff = steps[0].affine
+                flat = []
+                for s_ in steps:
+                    flat += [s_.norm.bias, s_.norm.logs, *s_.affine.nn_params()]
+                zc = z if z.stride(-1) == 1 and z.stride(1) == z.shape[2] * z.shape[3] else z.contiguous()
+                z, dl = K.GlowLevelFn.apply(zc, condition[l].contiguous(), W, K.ACT[aff.non_lin],
+                                            K.CLAMP[aff.clamp_type],
+                                            None if packs is None else [packs[s_] for s_ in steps], *flat)
+                dls.append(dl)
+                D.check("f.l%d.z" % l, z); D.check("f.l%d.dl" % l, dl)
+                steps_run = ()
+            else:
+                steps_run = steps
+            Wk = W.unbind(0) if (W is not None and steps_run) else None  # one stack-backward instead of K select-backward + K adds
+            for k, step in enumerate(steps_run):
                 if W is not None:
                     z, _ = step(z, condition[l], logdet=logdet, reverse=False, Wm=Wk[k], defer_logdet=dls,
                                 packs=None if packs is None else packs[step])

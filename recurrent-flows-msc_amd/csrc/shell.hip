@@ -111,6 +111,52 @@ extern "C" int rfn_channel_stats_f32(const float* x, long x_ns, float* mean, flo
     return 0;
 }
 
+__device__ __forceinline__ float clamp_ls(float s, int clamp_type, float sc, float sh) {
+    switch (clamp_type) {
+        case 0: return sc * tanhf(s) + sh;
+        case 1: return -log1pf(expf(-(s + 2.0f)));  // log sigmoid(s+2)
+        case 2: return 2.5f * 0.636f * atanf(s / 2.5f);
+        default: return s;
+    }
+}
+// d ls / d s
+__device__ __forceinline__ float clamp_ls_grad(float s, int clamp_type, float sc) {
+    switch (clamp_type) {
+        case 0: {
+            float t = tanhf(s);
+            return sc * (1.0f - t * t);
+        }
+        case 1: return 1.0f / (1.0f + expf(s + 2.0f));  // 1 - sigmoid(s+2)
+        case 2: {
+            float r = s / 2.5f;
+            return 0.636f / (1.0f + r * r);
+        }
+        default: return 1.0f;
+    }
+}
+
+
+// Backward of the affine coupling + Conv2dZeros epilogue of the PREVIOUS Glow step, appended to the ActNorm/InvConv
+// backward of this step (whose gx IS the previous step's output gradient and whose x IS its output): see
+// rfn_glow_shell_bwd_f32.
+struct ShellBwdTail {
+    const float* o;        // previous step's coupling-net output [N, C, HW]
+    long o_ns;
+    const float* glogdet;  // [N] or NULL
+    const float* scale;    // realnvp clamp parameters [C/2] (clamp_type 0)
+    const float* scale_shift;
+    const float* l3;       // Conv2dZeros logs [C]
+    float* gz;             // out: gradient wrt the previous step's post-InvConv tensor [N, C, HW] (whole tensor)
+    long gz_ns;
+    float* gpre;           // out: gradient at the previous step's conv3 output
+    long gpre_ns;
+    float* gscale;         // accumulated [C/2] (clamp_type 0)
+    float* gshift;
+    float* gb3;            // accumulated [C]
+    float* gl3;
+    int clamp_type;
+};
+
 // ------------------------------------------------------------------------------------------------ actnorm + invconv
 // A block owns PB consecutive "global pixels" q = n*HW + p.  y = (x+b)*exp(l) is staged in LDS as [C][PB]
 // (lane-consecutive pixels -> conflict free); every thread then forms the C outputs of its pixel with W read through
@@ -211,11 +257,15 @@ extern "C" int rfn_invconv_actnorm_rev_f32(const float* zin, long z_ns, const fl
 // block-level accumulators Wacc[C*C], Bacc[C], Lacc[C].  A block sweeps many pixel tiles (grid-stride) and issues its
 // global float atomics ONCE at the end: a few hundred blocks x (C*C + 2C) atomics instead of one set per 256 pixels —
 // same-address atomics serialise at the memory side (MI355X_MICROARCH.md "Global float atomics": 14x slower).
+// TAIL: the gx part runs over channel PAIRS (j, j + C/2) so that the thread that forms the previous step's output
+// gradient at both halves of a pair applies that step's coupling / Conv2dZeros-epilogue backward on the spot (gx itself
+// is not written).
+template <bool TAIL>
 __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
     const float* __restrict__ x, long x_ns, const float* __restrict__ bias, const float* __restrict__ logs,
     const float* __restrict__ Wm, const float* __restrict__ gz, long gz_ns, float* __restrict__ gx, long gx_ns,
     float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ glogs, int N, int C, int HW, int PB,
-    int ntiles) {
+    int ntiles, const ShellBwdTail tl) {
     extern __shared__ float lds[];
     const int PBS = PB + 1;
     float* Y = lds;                   // [C][PBS]
@@ -223,9 +273,10 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
     float* Wacc = lds + 2 * C * PBS;  // [C*C]
     float* Bacc = Wacc + C * C;       // [C]
     float* Lacc = Bacc + C;           // [C]
+    float* Tacc = Lacc + C;           // TAIL: [gb3 C][gl3 C][gscale C/2][gshift C/2]
     const int t = threadIdx.x;
     const int E = C * C;
-    for (int e = t; e < E + 2 * C; e += 256) Wacc[e] = 0.f;
+    for (int e = t; e < E + 2 * C + (TAIL ? 3 * C : 0); e += 256) Wacc[e] = 0.f;
     // all 256 threads stage: thread = (pixel px, channel group cg); PB is a power of two <= 256
     const int px = t & (PB - 1), cg = t / PB, ncg = 256 / PB;
     const long total = (long)N * HW;
@@ -270,7 +321,7 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
         // scalar cache and wave_sum adds over 64 pixels; masked pixels hold zeros.
         // The output channels are split over blockIdx.y as well (every y-block staged the same tile): at the deep levels a
         // launch has only a handful of pixel tiles and one block per tile ran C/ncg x C serial steps per thread.
-        {
+        if (!TAIL) {
             for (int j = cg + ncg * blockIdx.y; j < C; j += ncg * gridDim.y) {
                 float a = 0.f;
 #pragma unroll 8
@@ -282,6 +333,65 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
                 if ((t & 63) == 0) {
                     atomicAdd(&Bacc[j], s1);
                     atomicAdd(&Lacc[j], s2);
+                }
+            }
+        } else {
+            const int Ch = C >> 1;
+            for (int j = cg + ncg * blockIdx.y; j < Ch; j += ncg * gridDim.y) {
+                float a1 = 0.f, a2 = 0.f;
+#pragma unroll 8
+                for (int i = 0; i < C; ++i) {
+                    const float gv = G[i * PBS + px];
+                    a1 = fmaf(Wm[(long)i * C + j], gv, a1);
+                    a2 = fmaf(Wm[(long)i * C + j + Ch], gv, a2);
+                }
+                const float g1 = a1 * expf(logs[j]), g2 = a2 * expf(logs[j + Ch]);  // previous step's gout at (j, j+Ch)
+                // previous step: z2' = (z2 + o[2j]) * exp(ls(o[2j+1])), its output z2' is this step's x at channel j+Ch
+                float o0 = 0.f, sv = 0.f, zo = 0.f, gld = 0.f;
+                if (valid) {
+                    o0 = tl.o[n * tl.o_ns + (long)(2 * j) * HW + p];
+                    sv = tl.o[n * tl.o_ns + (long)(2 * j + 1) * HW + p];
+                    zo = xs[(long)(j + Ch) * HW];
+                    if (tl.glogdet) gld = tl.glogdet[n];
+                }
+                float sc = 0.f, sh = 0.f;
+                if (tl.clamp_type == 0) {
+                    sc = tl.scale[j];
+                    sh = tl.scale_shift[j];
+                }
+                const float ls = clamp_ls(sv, tl.clamp_type, sc, sh);
+                const float gls = valid ? g2 * zo + gld : 0.f;
+                const float gzv = g2 * expf(ls);
+                const float go1 = gls * clamp_ls_grad(sv, tl.clamp_type, sc);
+                const float u0 = gzv * expf(3.f * tl.l3[2 * j]), u1 = go1 * expf(3.f * tl.l3[2 * j + 1]);
+                if (valid) {
+                    tl.gz[n * tl.gz_ns + (long)j * HW + p] = g1;
+                    tl.gz[n * tl.gz_ns + (long)(j + Ch) * HW + p] = gzv;
+                    tl.gpre[n * tl.gpre_ns + (long)(2 * j) * HW + p] = u0;
+                    tl.gpre[n * tl.gpre_ns + (long)(2 * j + 1) * HW + p] = u1;
+                }
+                const float s1a = wave_sum(g1), s1b = wave_sum(g2);
+                const float s2a = wave_sum(a1 * Y[j * PBS + px]), s2b = wave_sum(a2 * Y[(j + Ch) * PBS + px]);
+                const float tb0 = wave_sum(u0), tb1 = wave_sum(u1);
+                const float tl0 = wave_sum(gzv * o0), tl1 = wave_sum(go1 * sv);
+                float tsc = 0.f, tsh = 0.f;
+                if (tl.clamp_type == 0) {
+                    tsc = wave_sum(gls * tanhf(sv));
+                    tsh = wave_sum(gls);
+                }
+                if ((t & 63) == 0) {
+                    atomicAdd(&Bacc[j], s1a);
+                    atomicAdd(&Bacc[j + Ch], s1b);
+                    atomicAdd(&Lacc[j], s2a);
+                    atomicAdd(&Lacc[j + Ch], s2b);
+                    atomicAdd(&Tacc[2 * j], tb0);
+                    atomicAdd(&Tacc[2 * j + 1], tb1);
+                    atomicAdd(&Tacc[C + 2 * j], 3.f * tl0);
+                    atomicAdd(&Tacc[C + 2 * j + 1], 3.f * tl1);
+                    if (tl.clamp_type == 0) {
+                        atomicAdd(&Tacc[2 * C + j], tsc);
+                        atomicAdd(&Tacc[2 * C + Ch + j], tsh);
+                    }
                 }
             }
         }
@@ -296,19 +406,30 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
     for (int c = t; c < C; c += 256) {  // channels this y-block did not compute hold zeros
         if (Bacc[c] != 0.f) atomicAdd(&gbias[c], Bacc[c]);
         if (Lacc[c] != 0.f) atomicAdd(&glogs[c], Lacc[c]);
+        if (TAIL) {
+            if (Tacc[c] != 0.f) atomicAdd(&tl.gb3[c], Tacc[c]);
+            if (Tacc[C + c] != 0.f) atomicAdd(&tl.gl3[c], Tacc[C + c]);
+            if (tl.clamp_type == 0) {
+                const int Ch = C >> 1;
+                float* dst = c < Ch ? tl.gscale + c : tl.gshift + (c - Ch);
+                if (Tacc[2 * C + c] != 0.f) atomicAdd(dst, Tacc[2 * C + c]);
+            }
+        }
     }
 }
 
 // Small channel counts (the two finest flow levels, C = 4 and 8, where N*HW is largest): one thread per pixel, all
 // C values in registers, every parameter-gradient partial in registers across a grid-stride sweep; the block's
 // C*C + 2C sums meet through wave shuffles + LDS and reach global memory as one atomic each.
-template <int C>
+template <int C, bool TAIL>
 __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
     const float* __restrict__ x, long x_ns, const float* __restrict__ bias, const float* __restrict__ logs,
     const float* __restrict__ Wm, const float* __restrict__ gz, long gz_ns, float* __restrict__ gx, long gx_ns,
-    float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ glogs, int N, int HW) {
-    __shared__ float red[C * C + 2 * C];
-    for (int e = threadIdx.x; e < C * C + 2 * C; e += 256) red[e] = 0.f;
+    float* __restrict__ gW, float* __restrict__ gbias, float* __restrict__ glogs, int N, int HW,
+    const ShellBwdTail tl) {
+    constexpr int Ch = C / 2;
+    __shared__ float red[C * C + 2 * C + 3 * C];  // TAIL: + [gb3 C][gl3 C][gscale Ch][gshift Ch]
+    for (int e = threadIdx.x; e < C * C + 2 * C + 3 * C; e += 256) red[e] = 0.f;
     __syncthreads();
     float w[C][C], b[C], es[C];
 #pragma unroll
@@ -319,21 +440,34 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
         for (int j = 0; j < C; ++j) w[i][j] = Wm[i * C + j];
     }
     float aW[C][C], ab[C], al[C];
+    float tb[C], tlg[C], tsc[Ch], tsh[Ch];  // TAIL accumulators
+    float sc[Ch], sh[Ch], e3[C];
 #pragma unroll
     for (int i = 0; i < C; ++i) {
         ab[i] = 0.f;
         al[i] = 0.f;
+        tb[i] = 0.f;
+        tlg[i] = 0.f;
+        e3[i] = TAIL ? expf(3.f * tl.l3[i]) : 1.f;
 #pragma unroll
         for (int j = 0; j < C; ++j) aW[i][j] = 0.f;
+    }
+#pragma unroll
+    for (int j = 0; j < Ch; ++j) {
+        tsc[j] = 0.f;
+        tsh[j] = 0.f;
+        sc[j] = (TAIL && tl.clamp_type == 0) ? tl.scale[j] : 0.f;
+        sh[j] = (TAIL && tl.clamp_type == 0) ? tl.scale_shift[j] : 0.f;
     }
     const long total = (long)N * HW;
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
         const long n = q / HW;
         const int p = (int)(q - n * HW);
-        float y[C], g[C];
+        float xr[C], y[C], g[C], gxr[C];
 #pragma unroll
         for (int c = 0; c < C; ++c) {
-            y[c] = (x[n * x_ns + (long)c * HW + p] + b[c]) * es[c];
+            xr[c] = x[n * x_ns + (long)c * HW + p];
+            y[c] = (xr[c] + b[c]) * es[c];
             g[c] = gz[n * gz_ns + (long)c * HW + p];
         }
 #pragma unroll
@@ -345,9 +479,35 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
                 aW[i][j] = fmaf(g[i], y[j], aW[i][j]);
             }
             const float gxv = gy * es[j];
-            gx[n * gx_ns + (long)j * HW + p] = gxv;
+            gxr[j] = gxv;
+            if (!TAIL) gx[n * gx_ns + (long)j * HW + p] = gxv;
             ab[j] += gxv;
             al[j] = fmaf(gy, y[j], al[j]);
+        }
+        if (TAIL) {
+            const float gld = tl.glogdet ? tl.glogdet[n] : 0.f;
+#pragma unroll
+            for (int j = 0; j < Ch; ++j) {
+                const float o0 = tl.o[n * tl.o_ns + (long)(2 * j) * HW + p];
+                const float sv = tl.o[n * tl.o_ns + (long)(2 * j + 1) * HW + p];
+                const float ls = clamp_ls(sv, tl.clamp_type, sc[j], sh[j]);
+                const float gls = gxr[j + Ch] * xr[j + Ch] + gld;
+                const float gzv = gxr[j + Ch] * expf(ls);
+                const float go1 = gls * clamp_ls_grad(sv, tl.clamp_type, sc[j]);
+                const float u0 = gzv * e3[2 * j], u1 = go1 * e3[2 * j + 1];
+                tl.gz[n * tl.gz_ns + (long)j * HW + p] = gxr[j];
+                tl.gz[n * tl.gz_ns + (long)(j + Ch) * HW + p] = gzv;
+                tl.gpre[n * tl.gpre_ns + (long)(2 * j) * HW + p] = u0;
+                tl.gpre[n * tl.gpre_ns + (long)(2 * j + 1) * HW + p] = u1;
+                tb[2 * j] += u0;
+                tb[2 * j + 1] += u1;
+                tlg[2 * j] = fmaf(gzv, o0, tlg[2 * j]);
+                tlg[2 * j + 1] = fmaf(go1, sv, tlg[2 * j + 1]);
+                if (tl.clamp_type == 0) {
+                    tsc[j] = fmaf(gls, tanhf(sv), tsc[j]);
+                    tsh[j] += gls;
+                }
+            }
         }
     }
     const bool lead = (threadIdx.x & 63) == 0;
@@ -363,36 +523,58 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
             atomicAdd(&red[C * C + i], vb);
             atomicAdd(&red[C * C + C + i], vl);
         }
+        if (TAIL) {
+            const float v0 = wave_sum(tb[i]), v1 = wave_sum(tlg[i]);
+            if (lead) {
+                atomicAdd(&red[C * C + 2 * C + i], v0);
+                atomicAdd(&red[C * C + 3 * C + i], 3.f * v1);
+            }
+        }
+    }
+    if (TAIL && tl.clamp_type == 0) {
+#pragma unroll
+        for (int j = 0; j < Ch; ++j) {
+            const float v0 = wave_sum(tsc[j]), v1 = wave_sum(tsh[j]);
+            if (lead) {
+                atomicAdd(&red[C * C + 4 * C + j], v0);
+                atomicAdd(&red[C * C + 4 * C + Ch + j], v1);
+            }
+        }
     }
     __syncthreads();
     for (int e = threadIdx.x; e < C * C; e += 256) atomicAdd(&gW[e], red[e]);
     if (threadIdx.x < C) {
         atomicAdd(&gbias[threadIdx.x], red[C * C + threadIdx.x]);
         atomicAdd(&glogs[threadIdx.x], red[C * C + C + threadIdx.x]);
+        if (TAIL) {
+            atomicAdd(&tl.gb3[threadIdx.x], red[C * C + 2 * C + threadIdx.x]);
+            atomicAdd(&tl.gl3[threadIdx.x], red[C * C + 3 * C + threadIdx.x]);
+            if (tl.clamp_type == 0) {
+                float* dst = threadIdx.x < Ch ? tl.gscale + threadIdx.x : tl.gshift + (threadIdx.x - Ch);
+                atomicAdd(dst, red[C * C + 4 * C + threadIdx.x]);
+            }
+        }
     }
 }
 
-extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const float* bias, const float* logs,
-                                           const float* Wm, const float* gz, long gz_ns, float* gx, long gx_ns,
-                                           float* gW, float* gbias, float* glogs, int N, int C, int HW,
-                                           rfn_stream_t stream) {
-    RFN_CHECK_ARG(x && bias && logs && Wm && gz && gx && gW && gbias && glogs && N >= 0 && C > 0 && HW > 0, -1);
-    if (N == 0) return 0;
+template <bool TAIL>
+static int launch_actnorm_invconv_bwd(const float* x, long x_ns, const float* bias, const float* logs, const float* Wm,
+                                      const float* gz, long gz_ns, float* gx, long gx_ns, float* gW, float* gbias,
+                                      float* glogs, int N, int C, int HW, const ShellBwdTail& tl, hipStream_t st) {
     if (C == 4 || C == 8) {
         long tot = (long)N * HW;
         // few, fat blocks: every block ends with C*C+2C same-address atomics, which serialise at the memory side
         int grid = (int)((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256);
         if (C == 4)
-            hipLaunchKernelGGL(actnorm_invconv_bwd_small_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, x_ns,
-                               bias, logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW);
+            hipLaunchKernelGGL((actnorm_invconv_bwd_small_kernel<4, TAIL>), dim3(grid), dim3(256), 0, st, x, x_ns, bias,
+                               logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW, tl);
         else
-            hipLaunchKernelGGL(actnorm_invconv_bwd_small_kernel<8>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, x_ns,
-                               bias, logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW);
-        RFN_LAUNCH_CHECK();
+            hipLaunchKernelGGL((actnorm_invconv_bwd_small_kernel<8, TAIL>), dim3(grid), dim3(256), 0, st, x, x_ns, bias,
+                               logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW, tl);
         return 0;
     }
     int PB = 256;
-    const size_t extra = ((size_t)C * C + 2 * C) * 4;
+    const size_t extra = ((size_t)C * C + 2 * C + (TAIL ? 3 * C : 0)) * 4;
     while ((size_t)2 * C * (PB + 1) * 4 + extra > 65536 && PB > 64) PB >>= 1;
     size_t lds = (size_t)2 * C * (PB + 1) * 4 + extra;
     if (lds > 160 * 1024) {
@@ -400,8 +582,8 @@ extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const floa
         return -3;
     }
     if (lds > 65536)
-        (void)hipFuncSetAttribute((const void*)actnorm_invconv_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  (int)lds);
+        (void)hipFuncSetAttribute((const void*)actnorm_invconv_bwd_kernel<TAIL>,
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     long tot = (long)N * HW;
     int ntiles = (int)((tot + PB - 1) / PB);
     int grid = ntiles < 512 ? ntiles : 512;
@@ -411,37 +593,48 @@ extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const floa
     if (ny < jpt / 2) ny = jpt / 2;
     if (ny > 8) ny = 8;
     while (ny > 1 && grid * ny > 2048) ny >>= 1;
-    hipLaunchKernelGGL(actnorm_invconv_bwd_kernel, dim3(grid, ny), dim3(256), lds, (hipStream_t)stream, x, x_ns, bias,
-                       logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB, ntiles);
+    hipLaunchKernelGGL(actnorm_invconv_bwd_kernel<TAIL>, dim3(grid, ny), dim3(256), lds, st, x, x_ns, bias, logs, Wm, gz,
+                       gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB, ntiles, tl);
+    return 0;
+}
+
+extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const float* bias, const float* logs,
+                                           const float* Wm, const float* gz, long gz_ns, float* gx, long gx_ns,
+                                           float* gW, float* gbias, float* glogs, int N, int C, int HW,
+                                           rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && bias && logs && Wm && gz && gx && gW && gbias && glogs && N >= 0 && C > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    ShellBwdTail tl = {};
+    int rc = launch_actnorm_invconv_bwd<false>(x, x_ns, bias, logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW,
+                                               tl, (hipStream_t)stream);
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Backward shell between two consecutive Glow steps in ONE launch: ActNorm + InvConv backward of step k+1 (x = its
+// input = step k's output, gz = gradient wrt its post-InvConv tensor) followed by the affine-coupling and Conv2dZeros
+// epilogue backward of step k, fed from registers (the gradient wrt step k's output never goes to HBM).
+extern "C" int rfn_glow_shell_bwd_f32(const float* x, long x_ns, const float* bias, const float* logs, const float* Wm,
+                                      const float* gz, long gz_ns, float* gW, float* gbias, float* glogs,
+                                      const float* o, long o_ns, const float* glogdet, const float* scale,
+                                      const float* scale_shift, const float* l3, float* gz_prev, long gz_prev_ns,
+                                      float* gpre, long gpre_ns, float* gscale, float* gscale_shift, float* gb3,
+                                      float* gl3, int clamp_type, int N, int C, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && bias && logs && Wm && gz && gW && gbias && glogs && N >= 0 && C > 0 && (C % 2 == 0) && HW > 0, -1);
+    RFN_CHECK_ARG(o && l3 && gz_prev && gpre && gb3 && gl3, -2);
+    RFN_CHECK_ARG(clamp_type != 0 || (scale && scale_shift && gscale && gscale_shift), -3);
+    if (N == 0) return 0;
+    ShellBwdTail tl = {o, o_ns, glogdet, scale, scale_shift, l3, gz_prev, gz_prev_ns, gpre, gpre_ns, gscale,
+                       gscale_shift, gb3, gl3, clamp_type};
+    int rc = launch_actnorm_invconv_bwd<true>(x, x_ns, bias, logs, Wm, gz, gz_ns, nullptr, 0, gW, gbias, glogs, N, C, HW,
+                                              tl, (hipStream_t)stream);
+    if (rc) return rc;
     RFN_LAUNCH_CHECK();
     return 0;
 }
 
 // ------------------------------------------------------------------------------------------------ affine coupling
-__device__ __forceinline__ float clamp_ls(float s, int clamp_type, float sc, float sh) {
-    switch (clamp_type) {
-        case 0: return sc * tanhf(s) + sh;
-        case 1: return -log1pf(expf(-(s + 2.0f)));  // log sigmoid(s+2)
-        case 2: return 2.5f * 0.636f * atanf(s / 2.5f);
-        default: return s;
-    }
-}
-// d ls / d s
-__device__ __forceinline__ float clamp_ls_grad(float s, int clamp_type, float sc) {
-    switch (clamp_type) {
-        case 0: {
-            float t = tanhf(s);
-            return sc * (1.0f - t * t);
-        }
-        case 1: return 1.0f / (1.0f + expf(s + 2.0f));  // 1 - sigmoid(s+2)
-        case 2: {
-            float r = s / 2.5f;
-            return 0.636f / (1.0f + r * r);
-        }
-        default: return 1.0f;
-    }
-}
-
 // one block per frame; elements e in [0, C/2*HW): channel j = e / HW
 __global__ __launch_bounds__(256) void affine_coupling_kernel(float* __restrict__ z, long z_ns,
                                                               const float* __restrict__ o, long o_ns,
@@ -617,6 +810,140 @@ extern "C" int rfn_gather_affine_f32(const float* P, const float* o_in, long o_n
     if (N == 0) return 0;
     hipLaunchKernelGGL(gather_affine_kernel, dim3(N), dim3(256), 0, (hipStream_t)stream, P, o_in, o_ns, b3, l3, o_out, z,
                        z_ns, scale, scale_shift, logdet, clamp_type, C, H, W);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// ---- forward shell between two consecutive Glow steps in ONE launch: the coupling tail of step k (tap gather / bias /
+// exp(3 logs) of its Conv2dZeros output, affine coupling in place, per-frame log-det ACCUMULATED) and the ActNorm +
+// InvConv head of step k+1 on the freshly coupled values (never re-read from HBM).  Either half may be absent: head only
+// (first step of a level), tail only (last step).  Block = PB consecutive global pixels, thread = (pixel, channel group).
+struct ShellFwdParams {
+    float* z;  // tail: step k's post-InvConv tensor, coupled in place (-> its output); head only: the head's input
+    long z_ns;
+    const float* P;     // tail, tap-expanded conv3 output [N, 9C, H, W] (then b3, l3, o_out are used) ...
+    const float* o_in;  // ... or the finished coupling-net output [N, C, H, W]
+    long o_ns;
+    const float* b3;
+    const float* l3;
+    float* o_out;
+    const float* scale;
+    const float* scale_shift;
+    float* logdet;  // [N], accumulated (atomicAdd)
+    int clamp_type, tail;
+    const float* bias;  // head: next step's ActNorm parameters and C x C matrix; znext = W ((v + bias) * exp(logs))
+    const float* logs;
+    const float* Wm;
+    float* znext;
+    long znext_ns;
+    int head;
+    int N, C, H, W, PB;
+};
+
+__global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParams q_) {
+    extern __shared__ float lds[];  // head: [C][PB]
+    const ShellFwdParams& a = q_;
+    const int PB = a.PB, C = a.C, Ch = C >> 1, HW = a.H * a.W;
+    const int px = threadIdx.x & (PB - 1), ig = threadIdx.x / PB, NG = 256 / PB;
+    const long q = (long)blockIdx.x * PB + px;
+    const bool valid = q < (long)a.N * HW;
+    int n = 0, p = 0;
+    if (valid) {
+        n = (int)(q / HW);
+        p = (int)(q % HW);
+    }
+    float* src = a.z + n * a.z_ns + p;
+    const int y = p / a.W, x = p - y * a.W;
+    float lsacc = 0.f;
+    for (int c = ig; c < C; c += NG) {
+        float v = valid ? src[(long)c * HW] : 0.f;
+        if (a.tail && c >= Ch && valid) {
+            const int j = c - Ch;
+            float shift, s;
+            if (a.P) {
+                const float* Pn = a.P + (long)n * 9 * C * HW;
+                float a0 = 0.f, a1 = 0.f;
+#pragma unroll
+                for (int t = 0; t < 9; ++t) {
+                    const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                    if (yy >= 0 && yy < a.H && xx >= 0 && xx < a.W) {
+                        const float* sp = Pn + ((long)t * C + 2 * j) * HW + (long)yy * a.W + xx;
+                        a0 += sp[0];
+                        a1 += sp[HW];
+                    }
+                }
+                shift = (a0 + a.b3[2 * j]) * expf(3.f * a.l3[2 * j]);
+                s = (a1 + a.b3[2 * j + 1]) * expf(3.f * a.l3[2 * j + 1]);
+                float* oo = a.o_out + (long)n * C * HW + p;
+                oo[(long)(2 * j) * HW] = shift;
+                oo[(long)(2 * j + 1) * HW] = s;
+            } else {
+                shift = a.o_in[n * a.o_ns + (long)(2 * j) * HW + p];
+                s = a.o_in[n * a.o_ns + (long)(2 * j + 1) * HW + p];
+            }
+            float sc = 0.f, sh = 0.f;
+            if (a.clamp_type == 0) {
+                sc = a.scale[j];
+                sh = a.scale_shift[j];
+            }
+            const float ls = clamp_ls(s, a.clamp_type, sc, sh);
+            v = (v + shift) * expf(ls);
+            src[(long)c * HW] = v;
+            lsacc += ls;
+        }
+        if (a.head) lds[c * PB + px] = (v + a.bias[c]) * expf(a.logs[c]);
+    }
+    if (a.tail) {
+        if ((HW & 63) == 0) {  // a wave's 64 pixels lie in one frame
+            const float tot = wave_sum(lsacc);
+            if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.logdet[n], tot);
+        } else if (valid && lsacc != 0.f) {
+            atomicAdd(&a.logdet[n], lsacc);
+        }
+    }
+    if (!a.head) return;
+    __syncthreads();
+    if (valid) {
+        float* dst = a.znext + n * a.znext_ns + p;
+        for (int i = ig; i < C; i += NG) {
+            float acc = 0.f;
+            const float* wr = a.Wm + (long)i * C;
+#pragma unroll 8
+            for (int j = 0; j < C; ++j) acc = fmaf(wr[j], lds[j * PB + px], acc);
+            dst[(long)i * HW] = acc;
+        }
+    }
+}
+
+extern "C" int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const float* o_in, long o_ns,
+                                      const float* b3, const float* l3, float* o_out, const float* scale,
+                                      const float* scale_shift, float* logdet, int clamp_type, const float* bias,
+                                      const float* logs, const float* Wm, float* znext, long znext_ns, int N, int C,
+                                      int H, int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(z && N >= 0 && C > 0 && (C % 2 == 0) && H > 0 && W > 0, -1);
+    const int tail = (P || o_in) ? 1 : 0, head = Wm ? 1 : 0;
+    RFN_CHECK_ARG(tail || head, -2);
+    RFN_CHECK_ARG(!tail || (logdet && ((P && b3 && l3 && o_out && !o_in) || (!P && o_in))), -3);
+    RFN_CHECK_ARG(!tail || clamp_type != 0 || (scale && scale_shift), -4);
+    RFN_CHECK_ARG(!head || (bias && logs && znext), -5);
+    if (N == 0) return 0;
+    const int HW = H * W;
+    int PB = shell_pb(C);
+    long tot = (long)N * HW;
+    while (PB > 32 && tot / PB < 256) PB >>= 1;
+    if (tail && PB < 64 && (HW & 63) == 0) PB = 64;  // the wave-level log-det reduction needs whole waves per pixel run
+    size_t lds = head ? (size_t)C * PB * 4 : 0;
+    if (lds > 160 * 1024) {
+        rfn_set_error("glow_shell_fwd: C=%d too large for the LDS-staged kernel", C);
+        return -6;
+    }
+    if (lds > 65536)
+        (void)hipFuncSetAttribute((const void*)glow_shell_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  (int)lds);
+    ShellFwdParams a = {z, z_ns, P, o_in, o_ns, b3, l3, o_out, scale, scale_shift, logdet, clamp_type, tail,
+                        bias, logs, Wm, znext, znext_ns, head, N, C, H, W, PB};
+    hipLaunchKernelGGL(glow_shell_fwd_kernel, dim3((unsigned)((tot + PB - 1) / PB)), dim3(256), lds, (hipStream_t)stream,
+                       a);
     RFN_LAUNCH_CHECK();
     return 0;
 }

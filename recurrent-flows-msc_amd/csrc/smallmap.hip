@@ -177,10 +177,12 @@ __device__ __forceinline__ void smallmap_dense_body(const SmallmapParams& p, flo
             }
             if (n < p.nsplit) {
                 float* dst = p.out + (long)row * p.out_ns + n;
-                if (p.acc1) s += *dst;
+                if (p.acc1 & 1) s += *dst;
                 *dst = s;
             } else {
-                p.out2[(long)row * p.out2_ns + (n - p.nsplit)] = s;
+                float* dst = p.out2 + (long)row * p.out2_ns + (n - p.nsplit);
+                if (p.acc1 & 2) s += *dst;
+                *dst = s;
             }
         }
     }

@@ -41,6 +41,10 @@ SIGNATURES = {
                               _c_i, _c_s],
     "rfn_affine_zeros_bwd_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f,
                                  _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_glow_shell_fwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f,
+                               _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_glow_shell_bwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f,
+                               _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_coupling_po_supported": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_coupling_po_packed_bytes": [_c_i, _c_i],
     "rfn_coupling_po_pack": [_c_f, _c_i, _c_s],

@@ -570,6 +570,118 @@ def conv_ep(in1, in2, w, p0, p1, ep_mode, act):
     return ConvFn.apply(in1, in2, w, p0, p1, ep_mode, act)
 
 
+def _f(t):
+    return None if t is None else t.detach().reshape(-1).contiguous()
+
+
+def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk):
+    """coupling network of one Glow step (glow_modules.py:232-238) on z's first channel half and `cond`.
+    Returns (h1, h2, o, P): either o (finished Conv2dZeros output) or P (its tap-expanded pre-gather form, fused forward
+    kernel) is None.  `pk`: the step's 7 pack-plan entries (see GlowStepFn.forward)."""
+    N, C, H, W = z.shape
+    Ch = C // 2
+    Hd = int(w1.shape[0])
+    z1 = z[:, :Ch]
+    cin2 = cond if cond.shape[1] > 0 else None
+    Cc_ = 0 if cin2 is None else int(cin2.shape[1])
+    k33 = int(w1.shape[2]) == 3 and int(w3.shape[2]) == 3
+    fp = fwd_prec(H, W)
+    if coupling_po_ok(N, C, Cc_, Hd, H, W, w1, w3) and int(w2.shape[2]) == 1:
+        # shallow levels: the whole coupling net in one kernel (csrc/coupling_po.hip), h1 / h2 written once
+        po = pk[6]
+        if po is None:
+            plan = POPackPlan([(w1.detach(), w2.detach(), w3.detach())])
+            plan.run()
+            po = plan.bufs[0]
+        h1, h2, P = coupling_po_fwd(z, cin2, po, _f(n1b), _f(n1l), _f(n2b), _f(n2l), C, act)
+        return h1, h2, None, P
+    # the two deepest levels (H*W <= 16): a launch is a few thousand pixels against megabytes of weights, the
+    # 3x3 convolutions go through the dense small-map kernels (bf16x3 arithmetic: only where that is allowed)
+    dense = k33 and smallmap_conv_ok(H, W, Ch, Cc_, Hd, N)
+    dense3 = k33 and smallmap_conv_ok(H, W, Hd, 0, C, N) and not zeros_conv_uses_taps(w3)
+    b3fwd = fp == "bf16x3"
+    if dense:
+        h1 = smallmap_conv(z1, cin2, smallmap_pack(w1, H, W, False), Hd, 1, _f(n1b), _f(n1l), act)
+    else:
+        h1 = conv2d_raw(z1, cin2, pk[0] if (pk[0] is not None and b3fwd) else pack_weight(w1, prec=fp), Hd,
+                        int(w1.shape[2]), 1, _f(n1b), _f(n1l), act, prec=fp)
+    h2 = conv2d_raw(h1, None, pk[2] if (pk[2] is not None and b3fwd) else pack_weight(w2, prec=fp), Hd,
+                    int(w2.shape[2]), 1, _f(n2b), _f(n2l), act, prec=fp)
+    if dense3:
+        o = smallmap_conv(h2, None, smallmap_pack(w3, H, W, False), C, 2, _f(b3), _f(l3), 0)
+    else:
+        o = zeros_conv_fwd(h2, w3, _f(b3), _f(l3), pk[4] if b3fwd else None, prec=fp)
+    return h1, h2, o, None
+
+
+def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gcond, acc_cond):
+    """backward of the coupling network from `go` = gradient at conv3's output: returns the parameter gradients
+    (gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3); the data gradient of conv1 is ADDED to gz[:, :C/2] and written (acc_cond:
+    added) to gcond."""
+    N, C, H, W = out.shape
+    Ch = C // 2
+    Hd = int(w1.shape[0])
+    Cc = int(cond.shape[1])
+    k1, k2, k3 = int(w1.shape[2]), int(w2.shape[2]), int(w3.shape[2])
+    gw3 = zeros_conv_wgrad(h2, go, C, k3, arena)
+    w3f = pk[5] if pk[5] is not None else pack_weight(w3, True)
+    w2f = pk[3] if pk[3] is not None else pack_weight(w2, True)
+    if bwd_b3() and Hd % 64 == 0:
+        # data-gradient convs with the backward of the producer's ActNorm+activation fused into their epilogue
+        gh2, gn2b, gn2l = conv2d_dgrad_act(go, w3f, h2, _f(n2l), act, Hd, k3)
+        gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
+        gh1, gn1b, gn1l = conv2d_dgrad_act(gh2, w2f, h1, _f(n1l), act, Hd, k2)
+    else:
+        gh2 = conv2d_raw(go, None, w3f, Hd, k3)
+        # ---- actnorm2 + act bwd, conv2 (1x1) bwd
+        gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, _f(n2l), 1, act, arena=arena)
+        gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
+        gh1 = conv2d_raw(gh2, None, w2f, Hd, k2)
+        # ---- actnorm1 + act bwd, conv1 bwd (grad flows to z1 (accumulated into gz's first half) and to cond)
+        gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, _f(n1l), 1, act, arena=arena)
+    z1 = out[:, :Ch]
+    has_cond = Cc > 0
+    gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
+    if k1 == 3 and k3 == 3 and smallmap_conv_ok(H, W, Hd, 0, Ch + Cc, N, bwd=True):
+        smallmap_conv(gh1, None, smallmap_pack(w1, H, W, True), Ch + Cc, 0, out1=gz[:, :Ch],
+                      out2=gcond if has_cond else None, cout_split=Ch, acc1=True, acc2=acc_cond)
+    else:
+        conv2d_raw(gh1, None, pk[1] if pk[1] is not None else pack_weight(w1, True), Ch + Cc, k1, 0,
+                   None, None, 0, out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True,
+                   acc2=acc_cond)
+    return gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3
+
+
+def _net_arena_numel(C, Cc, Hd, k1, k2, k3):
+    Ch = C // 2
+    return (2 * Ch + 8 + 3 * 2 * (Hd + 4) + 2 * (C + 4) + k1 * k1 * Hd * (Ch + Cc) + k2 * k2 * Hd * Hd
+            + max(k3 * k3 * C * Hd, 9 * C * Hd) + C * C + 2 * C + 64)
+
+
+def _affine_zeros_bwd(out, o, gout, gdl, scale, scale_shift, l3, clamp_type, arena):
+    """rfn_affine_zeros_bwd_f32: returns (gz, go, gscale, gshift, gb3, gl3)"""
+    N, C, H, W = out.shape
+    Ch, HW = C // 2, H * W
+    gz = torch.empty_like(gout)
+    go = torch.empty_like(o)
+    gscale = gshift = None
+    if clamp_type == 0:
+        gscale = arena.take(Ch)
+        gshift = arena.take(Ch)
+    gb3 = arena.take(C)
+    gl3 = arena.take(C)
+    op, ons = L.frames(o, "o")
+    outp, outns = L.frames(out, "out")
+    gop, gons = L.frames(gout, "gout")
+    gzp, gzns = L.frames(gz, "gz")
+    gonp, gonns = L.frames(go, "go")
+    scf, shf, l3f = _f(scale), _f(scale_shift), _f(l3)
+    L.call("rfn_affine_zeros_bwd_f32", outp, _l(outns), op, _l(ons), gop, _l(gons), L.dev(gdl), L.dev(scf),
+           L.dev(shf), L.dev(l3f), gzp, _l(gzns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), L.dev(gb3),
+           L.dev(gl3), _i(clamp_type), _i(N), _i(C), _i(HW), meta=_shell("affine_zeros_bwd", gout, 4.5))
+    return gz, go, gscale, gshift, gb3, gl3
+
+
 class GlowStepFn(torch.autograd.Function):
     """One forward Glow step (Flow/glow.py:31-36) as a single autograd node:
          y  = (x + an_bias) * exp(an_logs)                       glow_modules.py:38-45
@@ -580,7 +692,9 @@ class GlowStepFn(torch.autograd.Function):
          z2 <- (z2 + o[0::2]) * exp(clamp(o[1::2]))              glow_modules.py:276-285
        Returns (out, dlogdet[N]) where dlogdet holds only the data dependent Σ clamp(s) part; the parameter-only
        terms (Σlogs + Σlog_s)·H·W are added by the caller.
-       Saved for backward: x, cond, out, h1, h2, o (activations stay resident in HBM, 288 GB is plenty)."""
+       Saved for backward: x, cond, out, h1, h2, o (activations stay resident in HBM, 288 GB is plenty).
+       (The K steps of a level normally run as ONE node, GlowLevelFn; this one serves the first, data-initialising
+       call and stand-alone coupling layers.)"""
 
     @staticmethod
     def forward(ctx, x, cond, Wm, an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift,
@@ -588,46 +702,11 @@ class GlowStepFn(torch.autograd.Function):
         """`packs` (optional): (w1 fwd, w1 dgrad, w2 fwd, w2 dgrad, w3 fwd, w3 dgrad, fused-forward stream) packed
         buffers kept fresh by the caller's pack plans (entries may be None: packed on the fly); the forward entries are
         bf16x3 packs and only used where that is the forward arithmetic."""
-        N, C, H, W = x.shape
-        Ch = C // 2
-        Hd = int(w1.shape[0])
-        f = lambda t: None if t is None else t.detach().reshape(-1).contiguous()
-        out = actnorm_invconv_fwd(x, f(an_bias), f(an_logs), Wm.detach())
-        z1 = out[:, :Ch]
-        cin2 = cond if cond.shape[1] > 0 else None
+        out = actnorm_invconv_fwd(x, _f(an_bias), _f(an_logs), Wm.detach())
         pk = tuple(packs) + (None,) * (7 - len(packs)) if packs is not None else (None,) * 7
         ctx.packs = pk
-        Cc_ = 0 if cin2 is None else int(cin2.shape[1])
-        k33 = int(w1.shape[2]) == 3 and int(w3.shape[2]) == 3
-        fp = fwd_prec(H, W)
-        if coupling_po_ok(N, C, Cc_, Hd, H, W, w1, w3) and int(w2.shape[2]) == 1:
-            # shallow levels: the whole coupling net in one kernel (csrc/coupling_po.hip), h1 / h2 written once
-            po = pk[6]
-            if po is None:
-                plan = POPackPlan([(w1.detach(), w2.detach(), w3.detach())])
-                plan.run()
-                po = plan.bufs[0]
-            h1, h2, P = coupling_po_fwd(out, cin2, po, f(n1b), f(n1l), f(n2b), f(n2l), C, act)
-            o = None
-        else:
-            P = None
-            # the two deepest levels (H*W <= 16): a launch is a few thousand pixels against megabytes of weights, the
-            # 3x3 convolutions go through the dense small-map kernels (bf16x3 arithmetic: only where that is allowed)
-            dense = k33 and smallmap_conv_ok(H, W, Ch, Cc_, Hd, N)
-            dense3 = k33 and smallmap_conv_ok(H, W, Hd, 0, C, N) and not zeros_conv_uses_taps(w3)
-            b3fwd = fp == "bf16x3"
-            if dense:
-                h1 = smallmap_conv(z1, cin2, smallmap_pack(w1, H, W, False), Hd, 1, f(n1b), f(n1l), act)
-            else:
-                h1 = conv2d_raw(z1, cin2, pk[0] if (pk[0] is not None and b3fwd) else pack_weight(w1, prec=fp), Hd,
-                                int(w1.shape[2]), 1, f(n1b), f(n1l), act, prec=fp)
-            h2 = conv2d_raw(h1, None, pk[2] if (pk[2] is not None and b3fwd) else pack_weight(w2, prec=fp), Hd,
-                            int(w2.shape[2]), 1, f(n2b), f(n2l), act, prec=fp)
-            if dense3:
-                o = smallmap_conv(h2, None, smallmap_pack(w3, H, W, False), C, 2, f(b3), f(l3), 0)
-            else:
-                o = zeros_conv_fwd(h2, w3, f(b3), f(l3), pk[4] if b3fwd else None, prec=fp)
-        o, dlogdet = gather_affine_(out, o, P, f(b3), f(l3), f(scale), f(scale_shift), clamp_type)
+        h1, h2, o, P = _net_fwd(out, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk)
+        o, dlogdet = gather_affine_(out, o, P, _f(b3), _f(l3), _f(scale), _f(scale_shift), clamp_type)
         ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o)
         ctx.cfg = (act, clamp_type)
         return out, dlogdet
@@ -637,69 +716,151 @@ class GlowStepFn(torch.autograd.Function):
         (x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o) = ctx.saved_tensors
         act, clamp_type = ctx.cfg
         N, C, H, W = x.shape
-        Ch, HW = C // 2, H * W
-        Hd = int(w1.shape[0])
-        dev = x.device
-        f = lambda t: None if t is None else t.detach().reshape(-1).contiguous()
         gout = gout.contiguous()
         gdl = None if gdl is None else gdl.contiguous()
         Cc = int(cond.shape[1])
         k1, k2, k3 = int(w1.shape[2]), int(w2.shape[2]), int(w3.shape[2])
         # every accumulate-into output of this node lives in one zero-filled arena (1 fill launch instead of 14)
-        arena = ZeroArena(2 * Ch + 8 + 3 * 2 * (Hd + 4) + 2 * (C + 4) + k1 * k1 * Hd * (Ch + Cc) + k2 * k2 * Hd * Hd
-                          + max(k3 * k3 * C * Hd, 9 * C * Hd) + C * C + 2 * C + 64, dev)
-        # ---- affine coupling bwd + Conv2dZeros epilogue bwd in one launch: gz (whole tensor) and go = grad at conv3's output
-        gz = torch.empty_like(gout)
-        go = torch.empty_like(o)
-        gscale = gshift = None
-        if clamp_type == 0:
-            gscale = arena.take(Ch)
-            gshift = arena.take(Ch)
-        gb3 = arena.take(C)
-        gl3 = arena.take(C)
-        op, ons = L.frames(o, "o")
-        outp, outns = L.frames(out, "out")
-        gop, gons = L.frames(gout, "gout")
-        gzp, gzns = L.frames(gz, "gz")
-        gonp, gonns = L.frames(go, "go")
-        scf, shf, l3f = f(scale), f(scale_shift), f(l3)
-        L.call("rfn_affine_zeros_bwd_f32", outp, _l(outns), op, _l(ons), gop, _l(gons), L.dev(gdl), L.dev(scf),
-               L.dev(shf), L.dev(l3f), gzp, _l(gzns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), L.dev(gb3),
-               L.dev(gl3), _i(clamp_type), _i(N), _i(C), _i(HW), meta=_shell("affine_zeros_bwd", gout, 4.5))
-        gw3 = zeros_conv_wgrad(h2, go, C, k3, arena)
-        pk = ctx.packs
-        w3f = pk[5] if pk[5] is not None else pack_weight(w3, True)
-        w2f = pk[3] if pk[3] is not None else pack_weight(w2, True)
-        if bwd_b3() and Hd % 64 == 0:
-            # data-gradient convs with the backward of the producer's ActNorm+activation fused into their epilogue
-            gh2, gn2b, gn2l = conv2d_dgrad_act(go, w3f, h2, f(n2l), act, Hd, k3)
-            gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
-            gh1, gn1b, gn1l = conv2d_dgrad_act(gh2, w2f, h1, f(n1l), act, Hd, k2)
-        else:
-            gh2 = conv2d_raw(go, None, w3f, Hd, k3)
-            # ---- actnorm2 + act bwd, conv2 (1x1) bwd
-            gh2, gn2b, gn2l = conv_epilogue_bwd(h2, gh2, f(n2l), 1, act, arena=arena)
-            gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
-            gh1 = conv2d_raw(gh2, None, w2f, Hd, k2)
-            # ---- actnorm1 + act bwd, conv1 bwd (grad flows to z1 (accumulated into gz's first half) and to cond)
-            gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, f(n1l), 1, act, arena=arena)
-        z1 = out[:, :Ch]
-        has_cond = cond.shape[1] > 0
-        gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
-        gcond = torch.empty_like(cond) if has_cond else torch.zeros_like(cond)
-        if k1 == 3 and k3 == 3 and smallmap_conv_ok(H, W, Hd, 0, Ch + Cc, N, bwd=True):
-            smallmap_conv(gh1, None, smallmap_pack(w1, H, W, True), Ch + Cc, 0, out1=gz[:, :Ch],
-                          out2=gcond if has_cond else None, cout_split=Ch, acc1=True)
-        else:
-            conv2d_raw(gh1, None, pk[1] if pk[1] is not None else pack_weight(w1, True), Ch + int(cond.shape[1]), k1, 0,
-                       None, None, 0, out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True,
-                       acc2=False)
+        arena = ZeroArena(_net_arena_numel(C, Cc, int(w1.shape[0]), k1, k2, k3), x.device)
+        # ---- affine coupling bwd + Conv2dZeros epilogue bwd in one launch: gz (whole tensor), go = grad at conv3's output
+        gz, go, gscale, gshift, gb3, gl3 = _affine_zeros_bwd(out, o, gout, gdl, scale, scale_shift, l3, clamp_type, arena)
+        gcond = torch.empty_like(cond) if Cc > 0 else torch.zeros_like(cond)
+        gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3 = _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, ctx.packs,
+                                                         arena, gz, gcond, False)
         # ---- invconv + actnorm bwd
-        gx, gW, gab, gal = actnorm_invconv_bwd(x, f(an_bias), f(an_logs), Wm.detach(), gz, arena)
+        gx, gW, gab, gal = actnorm_invconv_bwd(x, _f(an_bias), _f(an_logs), Wm.detach(), gz, arena)
         return (gx, gcond, gW, gab.view(an_bias.shape), gal.view(an_logs.shape), gw1, gn1b.view(1, -1, 1, 1),
                 gn1l.view(n1l.shape), gw2, gn2b.view(1, -1, 1, 1), gn2l.view(n2l.shape), gw3, gb3, gl3.view(l3.shape),
                 None if gscale is None else gscale.view(scale.shape),
                 None if gshift is None else gshift.view(scale_shift.shape), None, None, None)
+
+
+STEP_NPARAM = 13  # an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift
+
+
+class GlowLevelFn(torch.autograd.Function):
+    """The K Glow steps of one flow level (Flow/glow.py:105-117, inner loop) as ONE autograd node.  Between two steps a
+    single launch each way does the shell work (rfn_glow_shell_fwd_f32: coupling tail of step k + ActNorm/InvConv head
+    of step k+1; rfn_glow_shell_bwd_f32: the mirror image); the gradient wrt the shared condition map accumulates
+    inside the data-gradient kernels and the per-frame log-det inside the shell kernel, so autograd adds nothing.
+    apply(x, cond, Wst[K,C,C], act, clamp_type, packs (list of K 7-tuples or None), *13K step parameters)
+    -> (out, dlogdet[N] = sum over the K steps of the data dependent log-det)."""
+
+    @staticmethod
+    def forward(ctx, x, cond, Wst, act, clamp_type, packs, *flat):
+        Kn = int(Wst.shape[0])
+        assert len(flat) == STEP_NPARAM * Kn
+        N, C, H, W = x.shape
+        prm = [flat[STEP_NPARAM * k:STEP_NPARAM * (k + 1)] for k in range(Kn)]
+        pks = [(tuple(packs[k]) + (None,) * 7)[:7] if packs is not None and packs[k] is not None else (None,) * 7
+               for k in range(Kn)]
+        Wd = Wst.detach().contiguous()
+        dl = torch.zeros(N, device=x.device, dtype=torch.float32)
+        xp, xns = L.frames(x, "x")
+        z = torch.empty_like(x)
+        zp, zns = L.frames(z, "z")
+        ab0, al0 = _f(prm[0][0]), _f(prm[0][1])
+        L.call("rfn_glow_shell_fwd_f32", xp, _l(xns), None, None, _l(0), None, None, None, None, None, None, _i(0),
+               L.dev(ab0), L.dev(al0), L.dev(Wd[0]), zp, _l(zns), _i(N), _i(C), _i(H), _i(W),
+               meta=_shell("glow_shell_fwd", x, 2))
+        outs, h1s, h2s, os_ = [], [], [], []
+        for k in range(Kn):
+            (_, _, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift) = prm[k]
+            h1, h2, o, P = _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pks[k])
+            last = k == Kn - 1
+            zn = None if last else torch.empty_like(z)
+            znp, znns = (None, 0) if last else L.frames(zn, "znext")
+            hold = [_f(b3), _f(l3), _f(scale), _f(scale_shift)] + ([None, None] if last else [_f(prm[k + 1][0]), _f(prm[k + 1][1])])
+            zp, zns = L.frames(z, "z")
+            if P is not None:
+                o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
+                args = (L.dev(P), None, _l(0), L.dev(hold[0]), L.dev(hold[1]), L.dev(o))
+                nt = 12 + (0 if last else 1)
+            else:
+                op, ons = L.frames(o, "o")
+                args = (None, op, _l(ons), None, None, None)
+                nt = 2 + (0 if last else 1.5)
+            L.call("rfn_glow_shell_fwd_f32", zp, _l(zns), *args, L.dev(hold[2]), L.dev(hold[3]), L.dev(dl),
+                   _i(clamp_type), L.dev(hold[4]), L.dev(hold[5]), None if last else L.dev(Wd[k + 1]), znp, _l(znns),
+                   _i(N), _i(C), _i(H), _i(W), meta=_shell("glow_shell_fwd", z, nt))
+            outs.append(z)
+            h1s.append(h1)
+            h2s.append(h2)
+            os_.append(o)
+            z = zn
+        ctx.save_for_backward(x, cond, Wst, *flat, *outs, *h1s, *h2s, *os_)
+        ctx.cfg = (act, clamp_type, Kn, pks)
+        return outs[-1], dl
+
+    @staticmethod
+    def backward(ctx, gout, gdl):
+        act, clamp_type, Kn, pks = ctx.cfg
+        sv = ctx.saved_tensors
+        x, cond, Wst = sv[0], sv[1], sv[2]
+        nf = STEP_NPARAM * Kn
+        flat = sv[3:3 + nf]
+        rest = sv[3 + nf:]
+        outs, h1s, h2s, os_ = (rest[i * Kn:(i + 1) * Kn] for i in range(4))
+        prm = [flat[STEP_NPARAM * k:STEP_NPARAM * (k + 1)] for k in range(Kn)]
+        N, C, H, W = x.shape
+        Ch, HW = C // 2, H * W
+        Cc = int(cond.shape[1])
+        gout = gout.contiguous()
+        gdl = None if gdl is None else gdl.contiguous()
+        Wd = Wst.detach().contiguous()
+        w1 = prm[0][2]
+        k1, k2, k3 = int(prm[0][2].shape[2]), int(prm[0][5].shape[2]), int(prm[0][8].shape[2])
+        # one zero-filled arena for the accumulate-into outputs of all K steps
+        arena = ZeroArena(Kn * _net_arena_numel(C, Cc, int(w1.shape[0]), k1, k2, k3), x.device)
+        gWst = arena.take(Kn, C, C)
+        gcond = torch.empty_like(cond) if Cc > 0 else torch.zeros_like(cond)
+        grads = [None] * nf
+        # last step: stand-alone coupling backward; earlier steps get theirs from the fused shell launch below
+        (_, _, _, _, _, _, _, _, _, _, l3, scale, scale_shift) = prm[Kn - 1]
+        gz, go, gscale, gshift, gb3, gl3 = _affine_zeros_bwd(outs[Kn - 1], os_[Kn - 1], gout, gdl, scale, scale_shift, l3,
+                                                            clamp_type, arena)
+        gx = None
+        for k in range(Kn - 1, -1, -1):
+            (an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift) = prm[k]
+            gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3 = _net_bwd(go, outs[k], cond, h1s[k], h2s[k], w1, n1l, w2, n2l, w3, act,
+                                                             pks[k], arena, gz, gcond, k != Kn - 1)
+            base = STEP_NPARAM * k
+            grads[base + 2:base + 13] = [gw1, gn1b.view(1, -1, 1, 1), gn1l.view(n1l.shape), gw2, gn2b.view(1, -1, 1, 1),
+                                         gn2l.view(n2l.shape), gw3, gb3, gl3.view(l3.shape),
+                                         None if gscale is None else gscale.view(scale.shape),
+                                         None if gshift is None else gshift.view(scale_shift.shape)]
+            gab, gal = arena.take(C), arena.take(C)
+            grads[base], grads[base + 1] = gab.view(an_bias.shape), gal.view(an_logs.shape)
+            abf, alf = _f(an_bias), _f(an_logs)
+            gzp, gzns = L.frames(gz, "gz")
+            if k == 0:
+                gx = torch.empty_like(x)
+                xp, xns = L.frames(x, "x")
+                gxp, gxns = L.frames(gx, "gx")
+                L.call("rfn_actnorm_invconv_bwd_f32", xp, _l(xns), L.dev(abf), L.dev(alf), L.dev(Wd[0]), gzp, _l(gzns),
+                       gxp, _l(gxns), L.dev(gWst[0]), L.dev(gab), L.dev(gal), _i(N), _i(C), _i(HW),
+                       meta=_shell("actnorm_invconv_bwd", x, 3))
+                break
+            # fused: ActNorm/InvConv backward of step k, coupling + Conv2dZeros-epilogue backward of step k-1
+            (_, _, _, _, _, _, _, _, _, _, l3p, scalep, shiftp) = prm[k - 1]
+            xin, op_ = outs[k - 1], os_[k - 1]
+            gzn = torch.empty_like(gz)
+            gon = torch.empty_like(op_)
+            gscale = gshift = None
+            if clamp_type == 0:
+                gscale, gshift = arena.take(Ch), arena.take(Ch)
+            gb3, gl3 = arena.take(C), arena.take(C)
+            xp, xns = L.frames(xin, "x")
+            opp, ons = L.frames(op_, "o")
+            gznp, gznns = L.frames(gzn, "gz_prev")
+            gonp, gonns = L.frames(gon, "gpre")
+            hold = [_f(scalep), _f(shiftp), _f(l3p)]
+            L.call("rfn_glow_shell_bwd_f32", xp, _l(xns), L.dev(abf), L.dev(alf), L.dev(Wd[k]), gzp, _l(gzns),
+                   L.dev(gWst[k]), L.dev(gab), L.dev(gal), opp, _l(ons), L.dev(gdl), L.dev(hold[0]), L.dev(hold[1]),
+                   L.dev(hold[2]), gznp, _l(gznns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), L.dev(gb3),
+                   L.dev(gl3), _i(clamp_type), _i(N), _i(C), _i(HW), meta=_shell("glow_shell_bwd", xin, 5.5))
+            gz, go = gzn, gon
+        return (gx, gcond, gWst, None, None, None) + tuple(grads)
 
 
 class GlowStepRevFn(torch.autograd.Function):
@@ -837,7 +998,7 @@ def smallmap_conv_ok(H, W, C1, C2, Cout, N, bwd=False):
 
 
 def smallmap_conv(in1, in2, packed, Cout, ep_mode=0, p0=None, p1=None, act=0, out1=None, out2=None, cout_split=None,
-                  acc1=False):
+                  acc1=False, acc2=False):
     """conv2d_raw's contract (3x3, pad 1) on an H*W <= 16 map through the dense split-precision product."""
     N, C1, H, W = in1.shape
     C2 = 0 if in2 is None else int(in2.shape[1])
@@ -850,7 +1011,7 @@ def smallmap_conv(in1, in2, packed, Cout, ep_mode=0, p0=None, p1=None, act=0, ou
     o1p, o1ns = L.frames(out1, "out1")
     o2p, o2ns = (None, 0) if out2 is None else L.frames(out2, "out2")
     L.call("rfn_smallmap_conv_bf16x3", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(packed), o1p, _l(o1ns), o2p,
-           _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(N), _i(H), _i(W), _i(ep_mode), L.dev(p0),
+           _l(o2ns), _i(Cout), _i(cout_split), _i((1 if acc1 else 0) | (2 if acc2 else 0)), _i(N), _i(H), _i(W), _i(ep_mode), L.dev(p0),
            L.dev(p1), _i(act),
            meta=("conv", "smallmap_dense_kernel", 2.0 * N * H * W * (C1 + C2) * Cout * 9,
                  "N%d %d+%d->%d %dx%d k3 ep%d dense" % (N, C1, C2, Cout, H, W, ep_mode),

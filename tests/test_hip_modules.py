@@ -880,3 +880,56 @@ def test_glowstep_bair_channel_counts(conv_precision, C, Cc, S):
         xb, ldb = gs(y, cu(c0), ld.clone(), True)
         close(xb, x0, 2e-4, 2e-5)
         assert float(ldb.abs().max()) <= 2e-4 * float(ld.abs().max()) + 1e-3
+
+
+@pytest.mark.parametrize("N,C,Cc,S,Hd,Kn,clamp", [(2, 4, 16, 32, 256, 3, "realnvp"), (3, 8, 32, 16, 256, 2, "glow"),
+                                               (5, 16, 8, 8, 64, 3, "realnvp"), (4, 32, 16, 4, 64, 2, "softclamp"),
+                                               (6, 64, 32, 2, 64, 3, "realnvp"), (3, 6, 0, 4, 64, 2, "none")])
+def test_glow_level_node_equals_chain_of_step_nodes(conv_precision, N, C, Cc, S, Hd, Kn, clamp):
+    """rfn_hip.ops.GlowLevelFn (the K steps of a level as one autograd node, shell work fused across step boundaries:
+    rfn_glow_shell_fwd_f32 / rfn_glow_shell_bwd_f32) against K chained GlowStepFn nodes -- outputs, log-det and every
+    gradient (input, shared condition, InvConv matrices, all step parameters).  The convolutions inside are the same
+    kernels on both sides, so the tolerance is that of fp32 sums in a different order: 1e-5 / 1e-4 of the range."""
+    from rfn_hip import ops as K
+    g = torch.Generator().manual_seed(40 + C)
+    Ch = C // 2
+    rn = clamp == "realnvp"
+
+    def leaf(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).cuda().requires_grad_(True)
+
+    x = leaf(N, C, S, S)
+    cond = leaf(N, Cc, S, S)
+    Wst = (torch.eye(C).expand(Kn, C, C) + 0.2 * torch.randn(Kn, C, C, generator=g)).cuda().requires_grad_(True)
+    steps = []
+    for _ in range(Kn):
+        steps.append([leaf(1, C, 1, 1, scale=0.1), leaf(1, C, 1, 1, scale=0.1),                      # actnorm
+                      leaf(Hd, Ch + Cc, 3, 3, scale=0.05), leaf(1, Hd, 1, 1, scale=0.1), leaf(1, Hd, 1, 1, scale=0.1),
+                      leaf(Hd, Hd, 1, 1, scale=0.05), leaf(1, Hd, 1, 1, scale=0.1), leaf(1, Hd, 1, 1, scale=0.1),
+                      leaf(C, Hd, 3, 3, scale=0.02), leaf(C, scale=0.1), leaf(C, 1, 1, scale=0.1),
+                      leaf(Ch, 1, 1, scale=0.5) if rn else None, leaf(Ch, 1, 1, scale=0.1) if rn else None])
+    act, ct = K.ACT["leakyrelu"], K.CLAMP[clamp]
+    gout = torch.randn(N, C, S, S, generator=g).cuda()
+    gdl = torch.randn(N, generator=g).cuda()
+    leaves = [x, cond, Wst] + [t for st in steps for t in st if t is not None]
+
+    def run(level):
+        for t in leaves:
+            t.grad = None
+        if level:
+            out, dl = K.GlowLevelFn.apply(x, cond, Wst, act, ct, None, *[t for st in steps for t in st])
+        else:
+            out, dl = x, 0
+            for k in range(Kn):
+                out, d = K.GlowStepFn.apply(out, cond, Wst[k], *steps[k], act, ct, None)
+                dl = dl + d
+        ((out * gout).sum() + (dl * gdl).sum()).backward()
+        return out.detach().clone(), dl.detach().clone(), [t.grad.detach().clone() for t in leaves]
+
+    o_ref, d_ref, g_ref = run(False)
+    o_lv, d_lv, g_lv = run(True)
+    close(o_lv, o_ref.cpu(), 1e-5, 1e-6)
+    close(d_lv, d_ref.cpu(), 1e-5, 1e-5)
+    for a, b in zip(g_lv, g_ref):
+        assert a.shape == b.shape
+        close(a, b.cpu(), 1e-4, 1e-6)
