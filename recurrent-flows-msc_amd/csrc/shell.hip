@@ -298,12 +298,13 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
         // gW[i][j] += Σ_p gz_i(p) y_j(p): small C -> 256/(C*C) threads per entry split the pixels (LDS atomic
         // combine); large C -> every thread owns entries e, e+256, ... (plain LDS read-modify-write, single owner)
         if (E <= 256) {
+            // (every y-block staged the same tile: the pixels of the tile are split over them)
             const int e = t % E, grp = t / E, G_ = 256 / E;
-            if (grp < G_ && blockIdx.y == 0) {
+            if (grp < G_) {
                 const float* gi = G + (e / C) * PBS;
                 const float* yj = Y + (e % C) * PBS;
                 float a = 0.f;
-                for (int pp = grp; pp < PB; pp += G_) a = fmaf(gi[pp], yj[pp], a);
+                for (int pp = grp + G_ * blockIdx.y; pp < PB; pp += G_ * gridDim.y) a = fmaf(gi[pp], yj[pp], a);
                 atomicAdd(&Wacc[e], a);
             }
         } else {
@@ -398,8 +399,7 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
     }
     __syncthreads();
     if (E <= 256) {
-        if (blockIdx.y == 0)
-            for (int e = t; e < E; e += 256) atomicAdd(&gW[e], Wacc[e]);
+        for (int e = t; e < E; e += 256) atomicAdd(&gW[e], Wacc[e]);
     } else {
         for (int e = blockIdx.y * 256 + t; e < E; e += 256 * gridDim.y) atomicAdd(&gW[e], Wacc[e]);  // owned entries
     }
@@ -842,6 +842,7 @@ struct ShellFwdParams {
 
 __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParams q_) {
     extern __shared__ float lds[];  // head: [C][PB]
+    __shared__ float fr[66];        // per-frame log-det partials of the block (maps smaller than a wave)
     const ShellFwdParams& a = q_;
     const int PB = a.PB, C = a.C, Ch = C >> 1, HW = a.H * a.W;
     const int px = threadIdx.x & (PB - 1), ig = threadIdx.x / PB, NG = 256 / PB;
@@ -897,6 +898,15 @@ __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParam
         if ((HW & 63) == 0) {  // a wave's 64 pixels lie in one frame
             const float tot = wave_sum(lsacc);
             if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.logdet[n], tot);
+        } else if (PB / HW + 2 <= 66) {
+            // small maps: a block spans a few frames; their sums meet in LDS and leave as ONE global atomic per frame
+            const int n0 = (int)(((long)blockIdx.x * PB) / HW);
+            for (int e = threadIdx.x; e < 66; e += 256) fr[e] = 0.f;
+            __syncthreads();
+            if (valid) atomicAdd(&fr[n - n0], lsacc);
+            __syncthreads();
+            if (threadIdx.x < 66 && n0 + (int)threadIdx.x < a.N && fr[threadIdx.x] != 0.f)
+                atomicAdd(&a.logdet[n0 + threadIdx.x], fr[threadIdx.x]);
         } else if (valid && lsacc != 0.f) {
             atomicAdd(&a.logdet[n], lsacc);
         }

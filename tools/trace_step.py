@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Developer tool: summarise the LAST training step of a rocprofv3 kernel trace (csv) by kernel family."""
 import collections, csv, glob, sys
-f = glob.glob(sys.argv[1] + "/*/*kernel_trace.csv")[0]
+f = (glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
 adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"].lower()]
@@ -24,8 +24,12 @@ def cat(n):
                             "convlstm", "channel_stats", "actnorm_invconv", "conv_epilogue")):
         return "MINE:shell"
     return n[:90]
+by_grid = len(sys.argv) > 3 and sys.argv[3] == "grid"  # keep launches of different grid sizes (= shapes) apart
 for r in seg:
-    a = agg[cat(r["Kernel_Name"])]
+    key = cat(r["Kernel_Name"])
+    if by_grid and "Grid_Size_X" in r:
+        key = "%s [grid %s,%s wg %s]" % (key[:70], r["Grid_Size_X"], r.get("Grid_Size_Y", "1"), r.get("Workgroup_Size_X", "?"))
+    a = agg[key]
     a[0] += 1
     a[1] += (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1e6
 for k, v in sorted(agg.items(), key=lambda kv: -kv[1][1])[:int(sys.argv[2]) if len(sys.argv) > 2 else 30]:
