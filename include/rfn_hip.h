@@ -166,6 +166,16 @@ int rfn_glow_shell_bwd_f32(const float* x, long x_ns, const float* bias, const f
                            float* gscale_shift, float* gb3, float* gl3, int clamp_type, int N, int C, int HW,
                            rfn_stream_t stream);
 
+/* ---- 3x3 convolution (stride 1, pad 1) with at most 64 output channels and Cin % 16 == 0 input channels on 32x32 or
+ * 16x16 maps, bf16x3 arithmetic, one input tensor: the data gradient of the first coupling-net convolution at the two
+ * finest flow levels (256 -> C/2 + Cc channels; backward of Flow/glow_modules.py:232-238).  wpk: the
+ * rfn_pack_conv_weight_bf16x3 buffer of the logical weight (transpose_flip = 1 of the forward weight for a data
+ * gradient).  Output channels [0, cout_split) go to out1, the rest to out2; acc1 / acc2: add into what is there. */
+int rfn_dgrad_small_supported(int N, int Cin, int Cout, int H, int W);
+int rfn_conv3x3_smallcout_bf16x3(const float* in, long in_ns, int Cin, const float* wpk, float* out1, long out1_ns,
+                                 float* out2, long out2_ns, int Cout, int cout_split, int acc1, int acc2, int N, int H,
+                                 int W, rfn_stream_t stream);
+
 /* Split-precision weight-gradient GEMM: gw[M][Nc] += Σ_{f,p} a[f][m][p] * b[f][n][p]  (a: [F,M,HW] frame stride a_ns,
  * b: [F,Nc,HW] frame stride b_ns; HW % 4 == 0, 16-byte aligned bases).  gw is accumulated with float atomics (caller
  * zeroes it).  1x1 weight gradients use it directly (a = output grad, b = conv input); 3x3 ones first expand the

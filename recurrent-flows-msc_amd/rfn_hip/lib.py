@@ -45,6 +45,9 @@ SIGNATURES = {
                                _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_glow_shell_bwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f,
                                _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_dgrad_small_supported": [_c_i, _c_i, _c_i, _c_i, _c_i],
+    "rfn_conv3x3_smallcout_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
+                                     _c_i, _c_s],
     "rfn_coupling_po_supported": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_coupling_po_packed_bytes": [_c_i, _c_i],
     "rfn_coupling_po_pack": [_c_f, _c_i, _c_s],

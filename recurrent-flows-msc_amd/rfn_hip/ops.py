@@ -574,6 +574,28 @@ def _f(t):
     return None if t is None else t.detach().reshape(-1).contiguous()
 
 
+def dgrad_small_ok(N, Cin, Cout, H, W, ks):
+    """the dedicated few-output-channel 3x3 kernel (csrc/dgrad_small.hip) serves this data-gradient convolution"""
+    return (ks == 3 and bwd_b3() and os.environ.get("RFN_DGRAD_SMALL") != "0"
+            and bool(L.load().rfn_dgrad_small_supported(int(N), int(Cin), int(Cout), int(H), int(W))))
+
+
+def conv3x3_smallcout(x, wpk, Cout, out1, out2=None, cout_split=None, acc1=False, acc2=False):
+    """rfn_conv3x3_smallcout_bf16x3: 3x3 / pad 1 convolution of x [N, Cin, H, W] with the packed weight `wpk`
+    (pack_weight(..., flip=True) for a data gradient) into out1 (channels [0, cout_split)) and out2 (the rest)."""
+    N, Cin, H, W = x.shape
+    if cout_split is None:
+        cout_split = Cout
+    xp, xns = L.frames(x, "x")
+    o1p, o1ns = L.frames(out1, "out1")
+    o2p, o2ns = (None, 0) if out2 is None else L.frames(out2, "out2")
+    L.call("rfn_conv3x3_smallcout_bf16x3", xp, _l(xns), _i(Cin), L.dev(wpk), o1p, _l(o1ns), o2p, _l(o2ns), _i(Cout),
+           _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W),
+           meta=("conv", "dgrad_small_kernel", 2.0 * N * H * W * Cin * Cout * 9,
+                 "N%d %d->%d %dx%d k3 dgrad" % (N, Cin, Cout, H, W), 4.0 * (N * H * W * (Cin + Cout) + Cin * Cout * 9)))
+    return out1
+
+
 def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk):
     """coupling network of one Glow step (glow_modules.py:232-238) on z's first channel half and `cond`.
     Returns (h1, h2, o, P): either o (finished Conv2dZeros output) or P (its tap-expanded pre-gather form, fused forward
@@ -645,6 +667,9 @@ def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gc
     if k1 == 3 and k3 == 3 and smallmap_conv_ok(H, W, Hd, 0, Ch + Cc, N, bwd=True):
         smallmap_conv(gh1, None, smallmap_pack(w1, H, W, True), Ch + Cc, 0, out1=gz[:, :Ch],
                       out2=gcond if has_cond else None, cout_split=Ch, acc1=True, acc2=acc_cond)
+    elif dgrad_small_ok(N, Hd, Ch + Cc, H, W, k1):
+        conv3x3_smallcout(gh1, pk[1] if pk[1] is not None else pack_weight(w1, True), Ch + Cc, gz[:, :Ch],
+                          gcond if has_cond else None, Ch, True, acc_cond)
     else:
         conv2d_raw(gh1, None, pk[1] if pk[1] is not None else pack_weight(w1, True), Ch + Cc, k1, 0,
                    None, None, 0, out1=gz[:, :Ch], out2=gcond if has_cond else None, cout_split=Ch, acc1=True,

@@ -227,6 +227,53 @@ def test_affine_kernel_fwd_rev(K, clamp):
     assert float(ld.abs().max()) < 1e-4
 
 
+@pytest.mark.parametrize("N,Cin,Cout,S,split,acc1,acc2", [
+    (70, 256, 18, 32, 2, True, False),    # level 0 of the canonical flow: dgrad of conv1 (256 -> 2 + 16)
+    (70, 256, 36, 16, 4, True, True),     # level 1 (256 -> 4 + 32), condition gradient accumulating
+    (3, 32, 18, 32, 18, False, False),    # single output tensor
+    (2, 64, 50, 32, 6, False, True),      # two output tiles at W = 32 (BAIR-like widths)
+    (5, 32, 7, 16, 3, True, False),       # two chunks, one output tile at W = 16
+    (609, 256, 18, 32, 2, True, True),    # more frames than CUs x 2, odd count
+])
+def test_conv3x3_smallcout_dgrad_kernel(K, N, Cin, Cout, S, split, acc1, acc2):
+    """rfn_conv3x3_smallcout_bf16x3 (csrc/dgrad_small.hip) as the data gradient of a forward conv [Cin -> Cout'] with
+    weight w [Cin, Cout, 3, 3]: against torch's conv_transpose2d / conv2d on the CPU in fp32 (N >= 70 shapes at the
+    BASELINE channel counts included).  bf16x3 arithmetic: 5e-5 of the output range."""
+    if not K.bwd_b3():
+        pytest.skip("bf16x3 backward arithmetic only")
+    g = torch.Generator().manual_seed(70 + Cout)
+    Nc = min(N, 8)  # the CPU reference covers the first frames and, for large N, the last ones
+    x = torch.randn(N, Cin, S, S, generator=g)
+    w = torch.randn(Cin, Cout, 3, 3, generator=g) * 0.05   # FORWARD weight of a conv Cout -> Cin
+    base1 = torch.randn(N, split, S, S, generator=g)
+    base2 = torch.randn(N, Cout - split, S, S, generator=g) if Cout > split else None
+    out1 = cu(base1.clone())
+    out2 = cu(base2.clone()) if base2 is not None else None
+    wd = cu(w)
+    K.conv3x3_smallcout(cu(x), K.pack_weight(wd, flip=True), Cout, out1, out2, split, acc1, acc2)
+
+    def ref(sl):
+        r = F.conv_transpose2d(x[sl], w, padding=1)  # = data gradient of conv2d(., w, padding=1)
+        r1 = r[:, :split] + (base1[sl] if acc1 else 0)
+        r2 = (r[:, split:] + (base2[sl] if acc2 else 0)) if base2 is not None else None
+        return r1, r2
+
+    for sl in (slice(0, Nc), slice(N - Nc, N)):
+        r1, r2 = ref(sl)
+        scale = float(r1.abs().max())
+        assert float((out1[sl].cpu() - r1).abs().max()) < 5e-5 * scale + 1e-6
+        if r2 is not None:
+            assert float((out2[sl].cpu() - r2).abs().max()) < 5e-5 * float(r2.abs().max()) + 1e-6
+    # and the generic kernel agrees (same arithmetic, different summation order)
+    g1 = cu(base1.clone())
+    g2 = cu(base2.clone()) if base2 is not None else None
+    K.conv2d_raw(cu(x), None, K.pack_weight(wd, flip=True), Cout, 3, 0, None, None, 0, out1=g1, out2=g2,
+                 cout_split=split, acc1=acc1, acc2=acc2)
+    assert relerr(out1, g1) < 2e-5
+    if g2 is not None:
+        assert relerr(out2, g2) < 2e-5
+
+
 @pytest.mark.parametrize("clamp", ["realnvp", "glow", "softclamp", "none"])
 @pytest.mark.parametrize("N,C,H,W", [(3, 4, 6, 6), (2, 8, 4, 4), (5, 64, 2, 2)])
 def test_fused_shell_tail_fwd_bwd(K, clamp, N, C, H, W):
