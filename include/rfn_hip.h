@@ -12,7 +12,11 @@
  *   - N is the number of frames in the launch (the host time-batches B*(T-1) frames), HW = H*W;
  *   - all functions enqueue on `stream` (a hipStream_t passed as void*) and never synchronise or allocate;
  *   - return value: 0 on success, otherwise a hipError_t / negative argument-check code; rfn_last_error() gives text;
- *   - no global state besides the last-error string; safe to call from several host threads on distinct streams.
+ *   - global state: the (thread-local) last-error string, and five developer knobs that the kernel selectors read ONCE
+ *     from the environment at their first call and then keep for the life of the process: RFN_CONV_WS (0: no
+ *     weight-stationary kernels), RFN_CONV_VARIANT, RFN_WGRAD_VARIANT, RFN_WGRAD_SPLIT, RFN_WGRAD_BPX128 (tile / split-K
+ *     experiments; unset = production choice).  They pick between kernels that compute the same result; nothing else is
+ *     cached between calls, and the library is safe to call from several host threads on distinct streams.
  */
 #ifndef RFN_HIP_H
 #define RFN_HIP_H
@@ -108,8 +112,9 @@ int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_st
 /* ---- a5 fused  AffineCoupling.net forward for the shallow levels (Flow/glow_modules.py:232-238 with :119-121 and
  * :139-142), csrc/coupling_po.hip: conv3x3 -> ActNorm -> act -> conv1x1 -> ActNorm -> act -> tap-expanded conv3x3 in
  * ONE kernel; the 256-channel hidden activations pass from layer to layer in registers (they are still written once:
- * the backward pass needs them).  Hidden layers: three bf16 pieces per operand, six MFMAs per product, fp32 accumulate
- * (fp32-equivalent); last layer: two pieces.
+ * the backward pass needs them).  Arithmetic "f16x3s": every operand is scaled by a power of two (per tensor for
+ * weights, per block for the staged input, per pixel for the hidden activations) and split into two fp16 pieces
+ * (22 significant bits); a product is three v_mfma_f32_32x32x16_f16 with fp32 accumulation, the scale undone in fp32.
  *   rfn_coupling_po_supported  1 when (N, C, Cc, Hd, H, W) is a shape the kernel takes (else use the unfused kernels);
  *   rfn_coupling_po_packed_bytes / rfn_coupling_po_pack  the fragment-ordered weight stream of one coupling net
  *       (descs_device: device array of n rfn_po_pack_desc; one launch packs every net of a flow);

@@ -174,7 +174,7 @@ class Solver(object):
             with torch.cuda.stream(side):
                 # three warm-ups of exactly the captured callable on a side stream: MIOpen / the autograd engine still
                 # initialise lazily on the 2nd-3rd execution of a backward, and doing that under capture crashes
-                for _ in range(3):
+                for _ in range(int(os.environ.get("RFN_CAPTURE_WARMUPS", "3"))):  # (developer knob: DESIGN.md §3)
                     self._graph_body()
                     self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.current_stream().wait_stream(side)

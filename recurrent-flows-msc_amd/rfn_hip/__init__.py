@@ -23,12 +23,13 @@ def _initial_environ_value(name):
     return None
 
 
-def _capture_safe(initial_value, value_at_import, hip_up_at_import):
+def _capture_safe(initial_value, value_at_import, hip_up_at_import, set_before_torch=False):
     """pure decision logic (unit tested): the flag certainly preceded HIP initialisation when the process was started
-    with it, or when it was already '0' while this package was imported and the runtime had not been brought up yet"""
+    with it, or when it was already '0' while this package was imported and the runtime had not been brought up yet, or
+    when an entry point of this repository set it before importing torch and says so (RFN_GRAPH_ENV_BEFORE_TORCH=1)"""
     if initial_value == "0":
         return True
-    return value_at_import == "0" and not hip_up_at_import
+    return value_at_import == "0" and (not hip_up_at_import or set_before_torch)
 
 
 def _hip_up():
@@ -39,7 +40,8 @@ def _hip_up():
         return False
 
 
-_STATE = (_initial_environ_value(GRAPH_ENV), os.environ.get(GRAPH_ENV), _hip_up())
+_STATE = (_initial_environ_value(GRAPH_ENV), os.environ.get(GRAPH_ENV), _hip_up(),
+          os.environ.get("RFN_GRAPH_ENV_BEFORE_TORCH") == "1")
 
 
 def graph_capture_safe():

@@ -1,8 +1,10 @@
 import os
 # ROCm 7.2: with graph packet capture on, hipGraph memset nodes (PyTorch multi-block reductions zero their semaphores
 # with one) race with neighbouring kernel nodes on replay; must be set before the HIP runtime initialises.
-os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
 import sys
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+if "torch" not in sys.modules:  # the flag certainly precedes the HIP runtime: tell rfn_hip.graph_capture_safe()
+    os.environ.setdefault("RFN_GRAPH_ENV_BEFORE_TORCH", "1")
 
 import pytest
 

@@ -530,7 +530,7 @@ def test_tap_expanded_zeros_conv_fwd_wgrad(K, N, Cin, C, H, W):
 @pytest.mark.parametrize("N,C,Cc,S,act", [(2, 4, 16, 32, 1), (4, 8, 32, 16, 2), (41, 4, 16, 32, 2), (3, 4, 20, 32, 1)])
 def test_coupling_po_fused_forward(K, N, C, Cc, S, act, conv_precision):
     """the fused coupling-net forward (csrc/coupling_po.hip: conv3x3 -> ActNorm -> act -> conv1x1 -> ActNorm -> act ->
-    tap-expanded conv3x3, hidden activations handed over in registers, 3-piece split arithmetic) against plain fp32
+    tap-expanded conv3x3, hidden activations handed over in registers, scaled two-piece fp16 arithmetic "f16x3s") against plain fp32
     torch ops on the CPU: h1, h2 and the Conv2dZeros output o = gather(P).  N=41 frames of 32x32 is 328 rounds, more
     than one per persistent workgroup; Cc=20 leaves padded input channels in the last 8-channel group.
     Tolerance: 2e-5 of the tensor's largest magnitude (fp32-equivalent arithmetic, different summation order)."""

@@ -207,6 +207,8 @@ def test_graph_capture_guard_logic():
     assert f("0", "0", True) and f("0", "0", False)
     assert f(None, "0", False)
     assert not f(None, "0", True)          # an integrator touched torch.cuda first, then imported the package
+    assert f(None, "0", True, True)        # ... unless an entry point set it before importing torch and says so
+    assert not f(None, "1", True, True)
     assert not f(None, None, False) and not f("1", "1", False)
     assert rfn_hip.graph_capture_safe() in (True, False)
     src = open(os.path.join(ROOT, "recurrent-flows-msc_amd", "rfn_hip", "__init__.py")).read()

@@ -12,6 +12,6 @@ write, n2 = mean_kb(sys.argv[2], "WRITE_SIZE", sys.argv[3])
 out = {"kernel": sys.argv[3], "dispatches": [n1, n2], "fetch_bytes_per_launch": 2.0 * fetch * 1024,
        "write_bytes_per_launch": write * 1024, "traffic_bytes_per_launch": (2.0 * fetch + write) * 1024,
        "corrections": "KB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B)",
-       "command": "rocprofv3 --pmc <counter> -- python3 bench.py --child --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-roofline"}
+       "command": "rocprofv3 --pmc <counter> -- python3 bench.py --child --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --secondary --no-parity"}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 print(json.dumps(out))
