@@ -90,9 +90,9 @@ int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, i
  * glow_modules.py:139-142 + Utils/modules.py:8-19): with y = act((u+b)*exp(logs)) saved from the forward pass,
  *   g  = conv(gin, wpk)                    (wpk packed with transpose_flip = 1 / mode 1)
  *   out = g * act'(y) * exp(logs[c])       (= grad wrt u, what the producer's weight- and data-gradient consume)
- *   part[row][0][c] = Σ out,  part[row][1][c] = Σ g*y   over the pixels of partial-sum row `row`
- * so grad b = Σ_rows part[.,0,c] and grad logs = Σ_rows part[.,1,c] need only a tiny reduction afterwards.
- * rows = rfn_conv2d_dgrad_act_rows_bf16x3(N,H,W,ks,Cout,Cin); part holds rows*Cout*2 floats; Cout % 64 == 0. */
+ *   part[0][c] += Σ out  (= grad b),  part[1][c] += Σ g*y  (= grad logs)   over all frames and pixels
+ * part is [2][Cout], accumulated with float atomics (one per workgroup / wave and channel): the caller zeroes it.
+ * Cout % 64 == 0.  (rfn_conv2d_dgrad_act_rows_bf16x3: number of partial sums per channel the launch adds; informative.) */
 int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int Cout, int Cin);
 int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Cin, const float* wpk, const float* y, long y_ns,
                                 const float* logs, int act, float* out, long out_ns, float* part, int Cout, int N,
@@ -189,7 +189,7 @@ int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long
                           rfn_stream_t stream);
 /* out[n][tap*Cin+ci][y][x] = in[n][ci][y+dy-1][x+dx-1] (0 outside); two-source input; out dense [N,9*Cin,H,W]. */
 /* 3x3 (pad 1) weight gradient without the im2col buffer (W % 8 == 0): gw[Cout][9*(C1+C2)] += sum over frames and
- * pixels of g[co][px] * in[ci][px + tap], column index tap*Cin + ci as for the GEMM on rfn_im2col3x3_f32's output.
+ * pixels of g[co][px] * in[ci][px + tap], column index ci*9 + tap: gw is the torch weight layout [Cout][Cin][3][3].
  * gw must be zeroed by the caller (split over pixel stages, atomic combine). */
 int rfn_conv3x3_wgrad_implicit_bf16x3(const float* g, long g_ns, int Cout, const float* in1, long in1_ns, int C1,
                                       const float* in2, long in2_ns, int C2, float* gw, int F, int H, int W,

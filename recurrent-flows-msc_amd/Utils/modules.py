@@ -99,6 +99,19 @@ def _act_code(m):
     return None
 
 
+_EMA_COEF = {}
+
+
+def _ema_coef(steps, m, n, device):
+    """m (1-m)^(S-1-t) for t = 0..S-1 (and the same times n/(n-1)), cached per (S, momentum, n, device)"""
+    key = (steps, float(m), int(n), str(device))
+    if key not in _EMA_COEF:
+        c = m * (1.0 - m) ** torch.arange(steps - 1, -1, -1, dtype=torch.float64)
+        _EMA_COEF[key] = (c.to(device=device, dtype=torch.float32),
+                          (c * (n / max(n - 1, 1))).to(device=device, dtype=torch.float32))
+    return _EMA_COEF[key]
+
+
 def per_step_batchnorm_act(bn, x, steps, act_code, slope):
     """per_step_batchnorm fused with the following activation on the HIP kernels (rfn_stepbn_*): no permute copies, one
     statistics pass and one normalise+activate pass forward, one reduction and one apply pass backward."""
@@ -108,10 +121,11 @@ def per_step_batchnorm_act(bn, x, steps, act_code, slope):
         with torch.no_grad():
             n = (x.shape[0] // steps) * x.shape[2] * x.shape[3]
             m = bn.momentum if bn.momentum is not None else 0.1
-            coef = m * (1.0 - m) ** torch.arange(steps - 1, -1, -1, device=x.device, dtype=x.dtype)
+            # r <- (1-m) r + m s_t for t = 0..steps-1  ==  (1-m)^S r + Σ_t m (1-m)^(S-1-t) s_t: one addmv per statistic
+            coef, coef_u = _ema_coef(steps, m, n, x.device)
             decay = (1.0 - m) ** steps
-            bn.running_mean.mul_(decay).add_((coef.view(steps, 1) * mean).sum(0))
-            bn.running_var.mul_(decay).add_((coef.view(steps, 1) * var).sum(0) * (n / max(n - 1, 1)))
+            bn.running_mean.addmv_(mean.t(), coef, beta=decay)
+            bn.running_var.addmv_(var.t(), coef_u, beta=decay)   # (biased batch variance -> unbiased: factor in coef_u)
             bn.num_batches_tracked += steps
     return y
 

@@ -437,7 +437,7 @@ extern "C" int rfn_conv2d_dgrad_act_rows_bf16x3(int N, int H, int W, int ks, int
 // data-gradient conv fused with the backward of the producer's Conv2dNorm epilogue (ActNorm + activation):
 //   g  = conv(gin, wpk)                      (wpk packed with transpose_flip = 1)
 //   gu = g * act'(y) * exp(logs[c])          -> out        (y = saved forward activation, same shape as out)
-//   part[row][0][c] = Σ_pixels(row) gu ,  part[row][1][c] = Σ g*y     (row < rfn_conv2d_dgrad_act_rows_bf16x3(...))
+//   part[0][c] += Σ_pixels gu ,  part[1][c] += Σ g*y     (float atomics; the caller zeroes part [2][Cout])
 // Cout must be a multiple of 64.
 extern "C" int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Cin, const float* wpk, const float* y,
                                            long y_ns, const float* logs, int act, float* out, long out_ns, float* part,
@@ -615,10 +615,10 @@ __global__ __launch_bounds__(512) void conv1x1_ws_kernel(const ConvParams p, con
         split_q(pvalid[0] ? q : 0, pn[0], ppix[0]);
         conv_epilogue<1, 1, 256>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile, psum);
     }
-    if (p.ep_mode == 4) {  // one row of partial sums per workgroup
+    if (p.ep_mode == 4) {  // the workgroup's partial sums: one atomic per (sum, channel)
         __syncthreads();
         for (int c = tid; c < 512; c += 512)  // psum is [256][2]; part rows are [2][Cout]
-            p.part[(long)blockIdx.x * 2 * p.Cout + (long)(c & 1) * p.Cout + blockIdx.y * 256 + (c >> 1)] = psum[c];
+            atomicAdd(&p.part[(long)(c & 1) * p.Cout + blockIdx.y * 256 + (c >> 1)], psum[c]);
     }
 }
 
@@ -773,10 +773,10 @@ __global__ __launch_bounds__(512) void conv3x3_ws_kernel(const ConvParams p, con
         }
         conv_epilogue<1, PT, 256, FASTEP>(p, acc, ep, co_base, wave, kk, HW, pn, ppix, pvalid, tile, psum);
     }
-    if (!FASTEP && p.ep_mode == 4) {  // one row of partial sums per workgroup
+    if (!FASTEP && p.ep_mode == 4) {  // the workgroup's partial sums: one atomic per (sum, channel)
         __syncthreads();
         for (int c = tid; c < 512; c += 512)  // psum is [256][2]; part rows are [2][Cout]
-            p.part[(long)blockIdx.x * 2 * p.Cout + (long)(c & 1) * p.Cout + blockIdx.y * 256 + (c >> 1)] = psum[c];
+            atomicAdd(&p.part[(long)(c & 1) * p.Cout + blockIdx.y * 256 + (c >> 1)], psum[c]);
     }
 }
 

@@ -30,7 +30,7 @@ struct ConvParams {
     // ep_mode 4 (data-gradient conv fused with the backward of the producer's ActNorm+activation epilogue):
     const float* ybuf;  // saved forward activation y = act((u+b)*exp(l)), same shape as the output
     long ybuf_ns;
-    float* part;        // [rows][2][Cout] partial sums: Σ gu, Σ g*y (rows: rfn_conv2d_dgrad_act_rows_bf16x3)
+    float* part;        // [2][Cout] sums Σ gu, Σ g*y, accumulated with float atomics (caller zeroes)
 };
 
 // Sum over each 32-lane half of a wave with DPP adds (VALU rate; __shfl_xor would go through the LDS crossbar, and the
@@ -111,9 +111,9 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                         dst[0] += sb;
                         dst[1] += sl;
                     } else {
-                        float* dst = p.part + (long)prow * 2 * p.Cout + co_base + cidx + 4 * kk;  // [row][2][Cout]
-                        dst[0] = sb;
-                        dst[p.Cout] = sl;
+                        float* dst = p.part + co_base + cidx + 4 * kk;  // [2][Cout], accumulated
+                        atomicAdd(dst, sb);
+                        atomicAdd(dst + p.Cout, sl);
                     }
                 }
             }

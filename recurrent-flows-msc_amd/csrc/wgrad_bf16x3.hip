@@ -22,7 +22,7 @@ struct GemmWgradParams {
     int F, HW;  // frames, pixels per frame (HW % 4 == 0)
     long total; // F*HW
     int n_stages;
-    // implicit 3x3 mode (IMPL = 1): operand B row n = tap*Cin + ci is the input plane ci shifted by the tap, read straight
+    // implicit 3x3 mode (IMPL = 1): operand B row n = ci*9 + tap is the input plane ci shifted by the tap, read straight
     // from the convolution's (two-source) input -- b = in1, b2 = in2 -- instead of from an im2col buffer in HBM
     const float* b2;
     long b2_ns;
@@ -80,12 +80,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
     float bedge[IMPL ? BU : 1];
     unsigned rowmask = 0, edgemask = 0;
     if (IMPL) {
-        const int Cin = p.C1 + p.C2;
 #pragma unroll
         for (int u = 0; u < BU; ++u) {
             int row = n0 + r0 + u * (NT / NU);
             if (row >= p.N) row = 0;
-            const int tap = row / Cin, ci = row - tap * Cin;
+            // row = ci*9 + tap: the output [Cout][9*Cin] IS the torch weight layout [Cout][Cin][3][3]
+            const int ci = row / 9, tap = row - ci * 9;
             udy[u] = tap / 3 - 1;
             udx[u] = tap % 3 - 1;
             const bool first = ci < p.C1;
@@ -289,9 +289,9 @@ extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const flo
     return 0;
 }
 
-// 3x3 weight gradient without the im2col buffer: gw[co][tap*Cin + ci] = sum_{frames,pixels} g[co][px] * in[ci][px + tap]
-// (pad 1), the shifted planes built while staging (rows of one image row, W % 8 == 0).  Same output layout as the GEMM on
-// rfn_im2col3x3_f32's buffer.
+// 3x3 weight gradient without the im2col buffer: gw[co][ci][tap] = sum_{frames,pixels} g[co][px] * in[ci][px + tap]
+// (pad 1), the shifted planes built while staging (rows of one image row, W % 8 == 0).  The output is the torch weight
+// layout [Cout][Cin][3][3] (the GEMM on rfn_im2col3x3_f32's buffer gives [Cout][tap][Cin] instead).
 extern "C" int rfn_conv3x3_wgrad_implicit_bf16x3(const float* g, long g_ns, int Cout, const float* in1, long in1_ns, int C1,
                                                  const float* in2, long in2_ns, int C2, float* gw, int F, int H, int W,
                                                  rfn_stream_t stream) {

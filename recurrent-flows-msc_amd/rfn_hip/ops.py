@@ -149,22 +149,21 @@ def pack_weight(w, flip=False, prec=None):
     return wpk
 
 
-def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks):
+def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks, arena=None):
     """data-gradient conv + backward through the producer's ActNorm/activation in one kernel
-    (rfn_conv2d_dgrad_act_bf16x3).  Returns (gu, grad_bias[Cout], grad_logs[Cout])."""
+    (rfn_conv2d_dgrad_act_bf16x3).  Returns (gu, grad_bias[Cout], grad_logs[Cout]); the two per-channel sums are
+    accumulated by the kernel (float atomics) into a zeroed [2, Cout] slice of `arena`."""
     N, Cin, H, W = gin.shape
     gp, gns = L.frames(gin, "gin")
     yp, yns = L.frames(y, "y")
     gu = torch.empty((N, Cout, H, W), device=gin.device, dtype=torch.float32)
     up, uns = L.frames(gu, "gu")
-    rows = L.load().rfn_conv2d_dgrad_act_rows_bf16x3(N, H, W, ks, Cout, Cin)
-    part = torch.empty((rows, 2, Cout), device=gin.device, dtype=torch.float32)
+    sums = _zeros(arena, 2, Cout, device=gin.device)
     L.call("rfn_conv2d_dgrad_act_bf16x3", gp, _l(gns), _i(Cin), L.dev(wpk_flip), yp, _l(yns), L.dev(logs), _i(act), up,
-           _l(uns), L.dev(part), _i(Cout), _i(N), _i(H), _i(W), _i(ks),
+           _l(uns), L.dev(sums), _i(Cout), _i(N), _i(H), _i(W), _i(ks),
            meta=("conv", conv_b3_kernel_name(Cout, ks, N * H * W, Cin, (H, W), True, True) + "+actbwd", 2.0 * N * H * W * Cin * Cout * ks * ks,
                  "N%d %d->%d %dx%d k%d dgrad+actbwd" % (N, Cin, Cout, H, W, ks),
                  4.0 * (N * H * W * (Cin + 2 * Cout) + Cin * Cout * ks * ks)))
-    sums = part.sum(0)  # [2, Cout]: contiguous rows, which AccumulateGrad can keep without a copy
     return gu, sums[0], sums[1]
 
 
@@ -372,7 +371,7 @@ def conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena=None):
                meta=("wgrad", "gemm_wgrad_b3_kernel<%s,1>" % ("4,2,2,3,64" if big else "2,2,2,2,64"),
                      2.0 * N * H * W * Cout * 9 * Cin, "F%d %dx%d HW%d implicit3x3" % (N, Cout, 9 * Cin, H * W),
                      4.0 * (N * H * W * (Cout + Cin) + Cout * 9 * Cin)))
-        return gw.view(Cout, 9, Cin).permute(0, 2, 1).reshape(Cout, Cin, 3, 3)
+        return gw.view(Cout, Cin, 3, 3)  # rows of the implicit operand are (ci, tap): already the torch layout
     if Cin <= Cout:
         i1p, i1ns = L.frames(in1, "in1")
         i2p, i2ns = (None, 0) if in2 is None else L.frames(in2, "in2")
@@ -650,9 +649,9 @@ def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gc
     w2f = pk[3] if pk[3] is not None else pack_weight(w2, True)
     if bwd_b3() and Hd % 64 == 0:
         # data-gradient convs with the backward of the producer's ActNorm+activation fused into their epilogue
-        gh2, gn2b, gn2l = conv2d_dgrad_act(go, w3f, h2, _f(n2l), act, Hd, k3)
+        gh2, gn2b, gn2l = conv2d_dgrad_act(go, w3f, h2, _f(n2l), act, Hd, k3, arena)
         gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
-        gh1, gn1b, gn1l = conv2d_dgrad_act(gh2, w2f, h1, _f(n1l), act, Hd, k2)
+        gh1, gn1b, gn1l = conv2d_dgrad_act(gh2, w2f, h1, _f(n1l), act, Hd, k2, arena)
     else:
         gh2 = conv2d_raw(go, None, w3f, Hd, k3)
         # ---- actnorm2 + act bwd, conv2 (1x1) bwd
