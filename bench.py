@@ -140,6 +140,13 @@ def kernel_roofline(rec, steps):
         with open(os.path.join(ROOT, "profiles", "r02_pmc_dominant_traffic.json")) as f:
             pmc = json.load(f)
         if pmc.get("kernel") and pmc["kernel"] in dom:
+            # the figure belongs to the kernel source it was measured on: dropped (null + traffic_stale) when that file changed
+            import hashlib
+            src = pmc.get("source")
+            cur = hashlib.sha256(open(os.path.join(ROOT, src), "rb").read()).hexdigest()[:16] if src else None
+            if src and cur != pmc.get("source_sha16"):
+                roof["traffic_stale"] = True
+                raise ValueError("stale")
             roof["traffic"] = pmc["traffic_bytes_per_launch"]
             roof["traffic_source"] = "profiles/r02_pmc_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes)"
     except (OSError, ValueError):

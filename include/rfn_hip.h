@@ -160,7 +160,9 @@ int rfn_affine_zeros_bwd_f32(const float* zout, long zout_ns, const float* o, lo
 int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const float* o_in, long o_ns, const float* b3,
                            const float* l3, float* o_out, const float* scale, const float* scale_shift, float* logdet,
                            int clamp_type, const float* bias, const float* logs, const float* Wm, float* znext,
-                           long znext_ns, int N, int C, int H, int W, rfn_stream_t stream);
+                           long znext_ns, int ld_const, int N, int C, int H, int W, rfn_stream_t stream);
+/* (ld_const = 1: the head also adds its ActNorm's parameter-only log-det term H*W * sum_c logs[c] to logdet[n],
+ * glow_modules.py:47-52; the backward kernels below then add H*W * sum_n glogdet[n] to glogs.) */
 /* Backward: rfn_actnorm_invconv_bwd_f32 of step k+1 (x = its input = step k's output, gz = gradient wrt its
  * post-InvConv tensor; gW, gbias, glogs accumulated) whose result feeds rfn_affine_zeros_bwd_f32 of step k from
  * registers (o .. gl3 are step k's, same meaning as there). */
@@ -168,8 +170,11 @@ int rfn_glow_shell_bwd_f32(const float* x, long x_ns, const float* bias, const f
                            const float* gz, long gz_ns, float* gW, float* gbias, float* glogs, const float* o, long o_ns,
                            const float* glogdet, const float* scale, const float* scale_shift, const float* l3,
                            float* gz_prev, long gz_prev_ns, float* gpre, long gpre_ns, float* gscale,
-                           float* gscale_shift, float* gb3, float* gl3, int clamp_type, int N, int C, int HW,
-                           rfn_stream_t stream);
+                           float* gscale_shift, float* gb3, float* gl3, int clamp_type, int ld_const, int N, int C,
+                           int HW, rfn_stream_t stream);
+int rfn_actnorm_invconv_bwd_ld_f32(const float* x, long x_ns, const float* bias, const float* logs, const float* Wm,
+                                   const float* gz, long gz_ns, float* gx, long gx_ns, float* gW, float* gbias,
+                                   float* glogs, const float* glogdet, int N, int C, int HW, rfn_stream_t stream);
 
 /* ---- 3x3 convolution (stride 1, pad 1) with at most 64 output channels and Cin % 16 == 0 input channels on 32x32 or
  * 16x16 maps, bf16x3 arithmetic, one input tensor: the data gradient of the first coupling-net convolution at the two

@@ -256,7 +256,9 @@ class ListGlow(nn.Module):
                 D.check("f.l%d.k%d.z" % (l, k), z)
                 if dls:
                     D.check("f.l%d.k%d.dl" % (l, k), dls[-1])
-            if W is not None:
+            if W is not None and not steps_run:
+                const = const + c  # (the level node adds the ActNorm terms H*W * sum logs itself)
+            elif W is not None:
                 # ActNorm logs are read AFTER the steps ran: the first training call initialises them in place
                 logs = torch.stack([s.norm.logs.reshape(-1) for s in steps])
                 const = const + c + logs.sum() * (z.shape[2] * z.shape[3])

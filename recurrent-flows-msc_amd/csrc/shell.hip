@@ -155,6 +155,8 @@ struct ShellBwdTail {
     float* gb3;            // accumulated [C]
     float* gl3;
     int clamp_type;
+    int ld_const;  // this step's ActNorm also contributes HW * sum_c logs[c] to every frame's log-det (added by the forward
+                   // shell kernel): its gradient HW * glogdet[n] is added to glogs here (glogdet must be given)
 };
 
 // ------------------------------------------------------------------------------------------------ actnorm + invconv
@@ -322,6 +324,8 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
         // scalar cache and wave_sum adds over 64 pixels; masked pixels hold zeros.
         // The output channels are split over blockIdx.y as well (every y-block staged the same tile): at the deep levels a
         // launch has only a handful of pixel tiles and one block per tile ran C/ncg x C serial steps per thread.
+        // gradient of the parameter-only log-det term HW * sum_c logs[c] (one contribution per frame: its pixel 0)
+        const float ldc = (tl.ld_const && valid && p == 0) ? (float)HW * tl.glogdet[n] : 0.f;
         if (!TAIL) {
             for (int j = cg + ncg * blockIdx.y; j < C; j += ncg * gridDim.y) {
                 float a = 0.f;
@@ -330,7 +334,7 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
                 const float gxv = a * expf(logs[j]);
                 if (valid) gx[n * gx_ns + (long)j * HW + p] = gxv;
                 const float s1 = wave_sum(gxv);
-                const float s2 = wave_sum(a * Y[j * PBS + px]);
+                const float s2 = wave_sum(a * Y[j * PBS + px] + ldc);
                 if ((t & 63) == 0) {
                     atomicAdd(&Bacc[j], s1);
                     atomicAdd(&Lacc[j], s2);
@@ -372,7 +376,7 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
                     tl.gpre[n * tl.gpre_ns + (long)(2 * j + 1) * HW + p] = u1;
                 }
                 const float s1a = wave_sum(g1), s1b = wave_sum(g2);
-                const float s2a = wave_sum(a1 * Y[j * PBS + px]), s2b = wave_sum(a2 * Y[(j + Ch) * PBS + px]);
+                const float s2a = wave_sum(a1 * Y[j * PBS + px] + ldc), s2b = wave_sum(a2 * Y[(j + Ch) * PBS + px] + ldc);
                 const float tb0 = wave_sum(u0), tb1 = wave_sum(u1);
                 const float tl0 = wave_sum(gzv * o0), tl1 = wave_sum(go1 * sv);
                 float tsc = 0.f, tsh = 0.f;
@@ -483,6 +487,11 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
             if (!TAIL) gx[n * gx_ns + (long)j * HW + p] = gxv;
             ab[j] += gxv;
             al[j] = fmaf(gy, y[j], al[j]);
+        }
+        if (tl.ld_const && p == 0) {
+            const float ldc = (float)HW * tl.glogdet[n];
+#pragma unroll
+            for (int c = 0; c < C; ++c) al[c] += ldc;
         }
         if (TAIL) {
             const float gld = tl.glogdet ? tl.glogdet[n] : 0.f;
@@ -612,6 +621,24 @@ extern "C" int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const floa
     return 0;
 }
 
+// rfn_actnorm_invconv_bwd_f32 for a step whose ActNorm also put HW * sum_c logs[c] into every frame's log-det (the level
+// node's forward shell kernel adds that term): glogs additionally receives HW * sum_n glogdet[n].
+extern "C" int rfn_actnorm_invconv_bwd_ld_f32(const float* x, long x_ns, const float* bias, const float* logs,
+                                              const float* Wm, const float* gz, long gz_ns, float* gx, long gx_ns,
+                                              float* gW, float* gbias, float* glogs, const float* glogdet, int N, int C,
+                                              int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && bias && logs && Wm && gz && gx && gW && gbias && glogs && N >= 0 && C > 0 && HW > 0, -1);
+    if (N == 0) return 0;
+    ShellBwdTail tl = {};
+    tl.glogdet = glogdet;
+    tl.ld_const = glogdet ? 1 : 0;
+    int rc = launch_actnorm_invconv_bwd<false>(x, x_ns, bias, logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW,
+                                               tl, (hipStream_t)stream);
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
 // Backward shell between two consecutive Glow steps in ONE launch: ActNorm + InvConv backward of step k+1 (x = its
 // input = step k's output, gz = gradient wrt its post-InvConv tensor) followed by the affine-coupling and Conv2dZeros
 // epilogue backward of step k, fed from registers (the gradient wrt step k's output never goes to HBM).
@@ -620,13 +647,14 @@ extern "C" int rfn_glow_shell_bwd_f32(const float* x, long x_ns, const float* bi
                                       const float* o, long o_ns, const float* glogdet, const float* scale,
                                       const float* scale_shift, const float* l3, float* gz_prev, long gz_prev_ns,
                                       float* gpre, long gpre_ns, float* gscale, float* gscale_shift, float* gb3,
-                                      float* gl3, int clamp_type, int N, int C, int HW, rfn_stream_t stream) {
+                                      float* gl3, int clamp_type, int ld_const, int N, int C, int HW,
+                                      rfn_stream_t stream) {
     RFN_CHECK_ARG(x && bias && logs && Wm && gz && gW && gbias && glogs && N >= 0 && C > 0 && (C % 2 == 0) && HW > 0, -1);
     RFN_CHECK_ARG(o && l3 && gz_prev && gpre && gb3 && gl3, -2);
     RFN_CHECK_ARG(clamp_type != 0 || (scale && scale_shift && gscale && gscale_shift), -3);
     if (N == 0) return 0;
     ShellBwdTail tl = {o, o_ns, glogdet, scale, scale_shift, l3, gz_prev, gz_prev_ns, gpre, gpre_ns, gscale,
-                       gscale_shift, gb3, gl3, clamp_type};
+                       gscale_shift, gb3, gl3, clamp_type, (ld_const && glogdet) ? 1 : 0};
     int rc = launch_actnorm_invconv_bwd<true>(x, x_ns, bias, logs, Wm, gz, gz_ns, nullptr, 0, gW, gbias, glogs, N, C, HW,
                                               tl, (hipStream_t)stream);
     if (rc) return rc;
@@ -838,6 +866,7 @@ struct ShellFwdParams {
     long znext_ns;
     int head;
     int N, C, H, W, PB;
+    int ld_const;  // head: also add the step's parameter-only log-det term HW * sum_c logs[c] to logdet[n]
 };
 
 __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParams q_) {
@@ -912,6 +941,11 @@ __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParam
         }
     }
     if (!a.head) return;
+    if (a.ld_const && valid && p == 0 && ig == 0) {  // once per frame
+        float cs = 0.f;
+        for (int c = 0; c < C; ++c) cs += a.logs[c];
+        atomicAdd(&a.logdet[n], cs * (float)HW);
+    }
     __syncthreads();
     if (valid) {
         float* dst = a.znext + n * a.znext_ns + p;
@@ -928,14 +962,15 @@ __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParam
 extern "C" int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const float* o_in, long o_ns,
                                       const float* b3, const float* l3, float* o_out, const float* scale,
                                       const float* scale_shift, float* logdet, int clamp_type, const float* bias,
-                                      const float* logs, const float* Wm, float* znext, long znext_ns, int N, int C,
-                                      int H, int W, rfn_stream_t stream) {
+                                      const float* logs, const float* Wm, float* znext, long znext_ns, int ld_const,
+                                      int N, int C, int H, int W, rfn_stream_t stream) {
     RFN_CHECK_ARG(z && N >= 0 && C > 0 && (C % 2 == 0) && H > 0 && W > 0, -1);
     const int tail = (P || o_in) ? 1 : 0, head = Wm ? 1 : 0;
     RFN_CHECK_ARG(tail || head, -2);
     RFN_CHECK_ARG(!tail || (logdet && ((P && b3 && l3 && o_out && !o_in) || (!P && o_in))), -3);
     RFN_CHECK_ARG(!tail || clamp_type != 0 || (scale && scale_shift), -4);
     RFN_CHECK_ARG(!head || (bias && logs && znext), -5);
+    RFN_CHECK_ARG(!ld_const || (head && logdet), -7);
     if (N == 0) return 0;
     const int HW = H * W;
     int PB = shell_pb(C);
@@ -951,7 +986,7 @@ extern "C" int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const
         (void)hipFuncSetAttribute((const void*)glow_shell_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     ShellFwdParams a = {z, z_ns, P, o_in, o_ns, b3, l3, o_out, scale, scale_shift, logdet, clamp_type, tail,
-                        bias, logs, Wm, znext, znext_ns, head, N, C, H, W, PB};
+                        bias, logs, Wm, znext, znext_ns, head, N, C, H, W, PB, ld_const};
     hipLaunchKernelGGL(glow_shell_fwd_kernel, dim3((unsigned)((tot + PB - 1) / PB)), dim3(256), lds, (hipStream_t)stream,
                        a);
     RFN_LAUNCH_CHECK();

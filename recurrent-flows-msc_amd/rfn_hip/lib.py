@@ -42,9 +42,11 @@ SIGNATURES = {
     "rfn_affine_zeros_bwd_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f,
                                  _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_glow_shell_fwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_f, _c_f, _c_f,
-                               _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_s],
+                               _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_glow_shell_bwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_f, _c_f,
-                               _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+                               _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_actnorm_invconv_bwd_ld_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_i,
+                                       _c_i, _c_i, _c_s],
     "rfn_dgrad_small_supported": [_c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_conv3x3_smallcout_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                      _c_i, _c_s],

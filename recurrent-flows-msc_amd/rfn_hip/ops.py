@@ -768,7 +768,8 @@ class GlowLevelFn(torch.autograd.Function):
     of step k+1; rfn_glow_shell_bwd_f32: the mirror image); the gradient wrt the shared condition map accumulates
     inside the data-gradient kernels and the per-frame log-det inside the shell kernel, so autograd adds nothing.
     apply(x, cond, Wst[K,C,C], act, clamp_type, packs (list of K 7-tuples or None), *13K step parameters)
-    -> (out, dlogdet[N] = sum over the K steps of the data dependent log-det)."""
+    -> (out, dlogdet[N] = sum over the K steps of the data dependent log-det AND of the ActNorm parameter term
+    H*W * sum_c logs[c]; the InvConv term sum log|s| * H*W stays with the caller, who builds the matrices)."""
 
     @staticmethod
     def forward(ctx, x, cond, Wst, act, clamp_type, packs, *flat):
@@ -784,8 +785,8 @@ class GlowLevelFn(torch.autograd.Function):
         z = torch.empty_like(x)
         zp, zns = L.frames(z, "z")
         ab0, al0 = _f(prm[0][0]), _f(prm[0][1])
-        L.call("rfn_glow_shell_fwd_f32", xp, _l(xns), None, None, _l(0), None, None, None, None, None, None, _i(0),
-               L.dev(ab0), L.dev(al0), L.dev(Wd[0]), zp, _l(zns), _i(N), _i(C), _i(H), _i(W),
+        L.call("rfn_glow_shell_fwd_f32", xp, _l(xns), None, None, _l(0), None, None, None, None, None, L.dev(dl), _i(0),
+               L.dev(ab0), L.dev(al0), L.dev(Wd[0]), zp, _l(zns), _i(1), _i(N), _i(C), _i(H), _i(W),
                meta=_shell("glow_shell_fwd", x, 2))
         outs, h1s, h2s, os_ = [], [], [], []
         for k in range(Kn):
@@ -806,7 +807,7 @@ class GlowLevelFn(torch.autograd.Function):
                 nt = 2 + (0 if last else 1.5)
             L.call("rfn_glow_shell_fwd_f32", zp, _l(zns), *args, L.dev(hold[2]), L.dev(hold[3]), L.dev(dl),
                    _i(clamp_type), L.dev(hold[4]), L.dev(hold[5]), None if last else L.dev(Wd[k + 1]), znp, _l(znns),
-                   _i(N), _i(C), _i(H), _i(W), meta=_shell("glow_shell_fwd", z, nt))
+                   _i(0 if last else 1), _i(N), _i(C), _i(H), _i(W), meta=_shell("glow_shell_fwd", z, nt))
             outs.append(z)
             h1s.append(h1)
             h2s.append(h2)
@@ -861,8 +862,8 @@ class GlowLevelFn(torch.autograd.Function):
                 gx = torch.empty_like(x)
                 xp, xns = L.frames(x, "x")
                 gxp, gxns = L.frames(gx, "gx")
-                L.call("rfn_actnorm_invconv_bwd_f32", xp, _l(xns), L.dev(abf), L.dev(alf), L.dev(Wd[0]), gzp, _l(gzns),
-                       gxp, _l(gxns), L.dev(gWst[0]), L.dev(gab), L.dev(gal), _i(N), _i(C), _i(HW),
+                L.call("rfn_actnorm_invconv_bwd_ld_f32", xp, _l(xns), L.dev(abf), L.dev(alf), L.dev(Wd[0]), gzp, _l(gzns),
+                       gxp, _l(gxns), L.dev(gWst[0]), L.dev(gab), L.dev(gal), L.dev(gdl), _i(N), _i(C), _i(HW),
                        meta=_shell("actnorm_invconv_bwd", x, 3))
                 break
             # fused: ActNorm/InvConv backward of step k, coupling + Conv2dZeros-epilogue backward of step k-1
@@ -882,7 +883,7 @@ class GlowLevelFn(torch.autograd.Function):
             L.call("rfn_glow_shell_bwd_f32", xp, _l(xns), L.dev(abf), L.dev(alf), L.dev(Wd[k]), gzp, _l(gzns),
                    L.dev(gWst[k]), L.dev(gab), L.dev(gal), opp, _l(ons), L.dev(gdl), L.dev(hold[0]), L.dev(hold[1]),
                    L.dev(hold[2]), gznp, _l(gznns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), L.dev(gb3),
-                   L.dev(gl3), _i(clamp_type), _i(N), _i(C), _i(HW), meta=_shell("glow_shell_bwd", xin, 5.5))
+                   L.dev(gl3), _i(clamp_type), _i(1), _i(N), _i(C), _i(HW), meta=_shell("glow_shell_bwd", xin, 5.5))
             gz, go = gzn, gon
         return (gx, gcond, gWst, None, None, None) + tuple(grads)
 
