@@ -192,6 +192,10 @@ int rfn_conv3x3_smallcout_bf16x3(const float* in, long in_ns, int Cin, const flo
  * smaller operand: b = rfn_im2col3x3_f32(input) [9*Cin rows, tap-major] or a = rfn_tap_scatter_f32(grad) [9*Cout rows]. */
 int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw, int F, int HW,
                           rfn_stream_t stream);
+/* G (<= 16) gradients of ONE shape in one launch (the K steps of a flow level, where a single gradient is a
+ * latency-class problem): a, b, gw are host arrays of G device pointers; strides and sizes are shared. */
+int rfn_gemm_wgrad_grouped_bf16x3(const float* const* a, long a_ns, int M, const float* const* b, long b_ns, int Nc,
+                                  float* const* gw, int G, int F, int HW, rfn_stream_t stream);
 /* out[n][tap*Cin+ci][y][x] = in[n][ci][y+dy-1][x+dx-1] (0 outside); two-source input; out dense [N,9*Cin,H,W]. */
 /* 3x3 (pad 1) weight gradient without the im2col buffer (W % 8 == 0): gw[Cout][9*(C1+C2)] += sum over frames and
  * pixels of g[co][px] * in[ci][px + tap], column index ci*9 + tap: gw is the torch weight layout [Cout][Cin][3][3].
@@ -199,6 +203,9 @@ int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long
 int rfn_conv3x3_wgrad_implicit_bf16x3(const float* g, long g_ns, int Cout, const float* in1, long in1_ns, int C1,
                                       const float* in2, long in2_ns, int C2, float* gw, int F, int H, int W,
                                       rfn_stream_t stream);
+int rfn_conv3x3_wgrad_implicit_grouped_bf16x3(const float* const* g, long g_ns, int Cout, const float* const* in1,
+                                              long in1_ns, int C1, const float* const* in2, long in2_ns, int C2,
+                                              float* const* gw, int G, int F, int H, int W, rfn_stream_t stream);
 int rfn_im2col3x3_f32(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2, float* out, int N,
                       int H, int W, rfn_stream_t stream);
 

@@ -27,6 +27,13 @@ struct GemmWgradParams {
     const float* b2;
     long b2_ns;
     int C1, C2, H, W;
+    // grouped launch (G > 0): G independent gradients of the SAME shape in one launch -- the K steps of a flow level at
+    // the deep levels / small batches, where a single gradient is a latency-class problem.  blockIdx.z = grp * mtiles + mt.
+    int G, mtiles;
+    const float* ga[16];
+    const float* gb[16];
+    const float* gb2[16];
+    float* ggw[16];
 };
 
 // WM x WN waves (4 or 8) of TM x TN 32x32 tiles each.  The 8-wave 256-row configurations read both operands of the
@@ -50,7 +57,12 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, kk = lane >> 5;
-    const int m0 = blockIdx.z * BM, n0 = blockIdx.y * BN;
+    const int grp = p.G > 0 ? (int)blockIdx.z / p.mtiles : 0;
+    const int m0 = (p.G > 0 ? (int)blockIdx.z - grp * p.mtiles : (int)blockIdx.z) * BM, n0 = blockIdx.y * BN;
+    const float* const pa_ = p.G > 0 ? p.ga[grp] : p.a;
+    const float* const pb_ = p.G > 0 ? p.gb[grp] : p.b;
+    const float* const pb2_ = p.G > 0 ? p.gb2[grp] : p.b2;
+    float* const pgw_ = p.G > 0 ? p.ggw[grp] : p.gw;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -89,7 +101,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
             udy[u] = tap / 3 - 1;
             udx[u] = tap % 3 - 1;
             const bool first = ci < p.C1;
-            uplane[u] = first ? p.b + (long)ci * p.HW : p.b2 + (long)(ci - p.C1) * p.HW;
+            uplane[u] = first ? pb_ + (long)ci * p.HW : pb2_ + (long)(ci - p.C1) * p.HW;
             uns[u] = first ? p.b_ns : p.b2_ns;
         }
     }
@@ -108,7 +120,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 #pragma unroll
         for (int u = 0; u < AU; ++u) {
             const int row = m0 + r0 + u * (NT / NU);
-            const float* base = p.a + (long)(row < p.M ? row : 0) * p.HW;
+            const float* base = pa_ + (long)(row < p.M ? row : 0) * p.HW;
 #pragma unroll
             for (int h = 0; h < 2; ++h) ast[u][h] = *reinterpret_cast<const float4*>(base + offa[h]);
         }
@@ -134,7 +146,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 #pragma unroll
             for (int u = 0; u < BU; ++u) {
                 const int row = n0 + r0 + u * (NT / NU);
-                const float* base = p.b + (long)(row < p.N ? row : 0) * p.HW;
+                const float* base = pb_ + (long)(row < p.N ? row : 0) * p.HW;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) bst[u][h] = *reinterpret_cast<const float4*>(base + offb[h]);
             }
@@ -232,7 +244,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (m < p.M && n < p.N) atomicAdd(&p.gw[(long)m * p.N + n], acc[i][j][r]);
+                if (m < p.M && n < p.N) atomicAdd(&pgw_[(long)m * p.N + n], acc[i][j][r]);
             }
         }
 }
@@ -247,27 +259,19 @@ static void launch_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
     // of atomic bytes -- 1024 workgroups x 64 KB is 50 us of atomics on a problem whose GEMM takes 10.  So: as many
     // workgroups as the CUs can hold at once (8-wave tiles: one per CU, 4-wave: two), and at least 4 stages each.
     static const int sdiv = getenv("RFN_WGRAD_SPLIT") ? atoi(getenv("RFN_WGRAD_SPLIT")) : 0;
-    int S = (sdiv > 0 ? sdiv : (WM * WN == 8 ? 256 : 512)) / tiles;
+    const int G = p.G > 0 ? p.G : 1;
+    int S = (sdiv > 0 ? sdiv : (WM * WN == 8 ? 256 : 512)) / (tiles * G);
     if (S > p.n_stages / 4) S = p.n_stages / 4;
     if (S < 1) S = 1;
     auto kern = gemm_wgrad_b3_kernel<WM, WN, TM, TN, KP, IMPL>;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
+    p.mtiles = ceil_div(p.M, BM);
+    dim3 grid(S, ceil_div(p.N, BN), p.mtiles * G);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
 }
 
-extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw,
-                                     int F, int HW, rfn_stream_t stream) {
-    RFN_CHECK_ARG(a && b && gw && M > 0 && Nc > 0 && F >= 0 && HW > 0, -1);
-    RFN_CHECK_ARG(HW % 4 == 0 && a_ns % 4 == 0 && b_ns % 4 == 0, -2);
-    RFN_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0, -3);
-    RFN_CHECK_ARG((long)F * HW < (1L << 31) - 4096, -4);
-    if (F == 0) return 0;
-    GemmWgradParams p;
-    memset(&p, 0, sizeof(p));
-    p.a = a; p.b = b; p.a_ns = a_ns; p.b_ns = b_ns; p.M = M; p.N = Nc; p.gw = gw; p.F = F; p.HW = HW;
-    p.total = (long)F * HW;
-    hipStream_t s = (hipStream_t)stream;
+static void select_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
+    const int M = p.M, Nc = p.N;
     static const int variant = getenv("RFN_WGRAD_VARIANT") ? atoi(getenv("RFN_WGRAD_VARIANT")) : 0;
     const bool big = variant != 1 && M > 128 && Nc > 128 && p.total >= 100000;
     if (big && ceil_div(Nc, 192) * 192 < ceil_div(Nc, 256) * 256) {
@@ -285,6 +289,41 @@ extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const flo
         launch_gemm_wgrad<4, 1, 2, 2, 32>(p, s);   // 256 x 64
     else
         launch_gemm_wgrad<2, 2, 2, 2, 64>(p, s);   // 128 x 128
+}
+
+extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw,
+                                     int F, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(a && b && gw && M > 0 && Nc > 0 && F >= 0 && HW > 0, -1);
+    RFN_CHECK_ARG(HW % 4 == 0 && a_ns % 4 == 0 && b_ns % 4 == 0, -2);
+    RFN_CHECK_ARG((((uintptr_t)a | (uintptr_t)b) & 15) == 0, -3);
+    RFN_CHECK_ARG((long)F * HW < (1L << 31) - 4096, -4);
+    if (F == 0) return 0;
+    GemmWgradParams p;
+    memset(&p, 0, sizeof(p));
+    p.a = a; p.b = b; p.a_ns = a_ns; p.b_ns = b_ns; p.M = M; p.N = Nc; p.gw = gw; p.F = F; p.HW = HW;
+    p.total = (long)F * HW;
+    select_gemm_wgrad(p, (hipStream_t)stream);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// G (<= 16) weight gradients of one shape in ONE launch: gw[g][M][Nc] += sum a[g] b[g]^T (same strides, F, HW for all).
+extern "C" int rfn_gemm_wgrad_grouped_bf16x3(const float* const* a, long a_ns, int M, const float* const* b, long b_ns,
+                                             int Nc, float* const* gw, int G, int F, int HW, rfn_stream_t stream) {
+    RFN_CHECK_ARG(a && b && gw && G >= 1 && G <= 16 && M > 0 && Nc > 0 && F >= 0 && HW > 0, -1);
+    RFN_CHECK_ARG(HW % 4 == 0 && a_ns % 4 == 0 && b_ns % 4 == 0, -2);
+    RFN_CHECK_ARG((long)F * HW < (1L << 31) - 4096, -4);
+    if (F == 0) return 0;
+    GemmWgradParams p;
+    memset(&p, 0, sizeof(p));
+    for (int g = 0; g < G; ++g) {
+        RFN_CHECK_ARG(a[g] && b[g] && gw[g] && (((uintptr_t)a[g] | (uintptr_t)b[g]) & 15) == 0, -3);
+        p.ga[g] = a[g]; p.gb[g] = b[g]; p.gb2[g] = b[g]; p.ggw[g] = gw[g];
+    }
+    p.G = G; p.a = a[0]; p.b = b[0]; p.gw = gw[0];
+    p.a_ns = a_ns; p.b_ns = b_ns; p.M = M; p.N = Nc; p.F = F; p.HW = HW;
+    p.total = (long)F * HW;
+    select_gemm_wgrad(p, (hipStream_t)stream);
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -292,6 +331,13 @@ extern "C" int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const flo
 // 3x3 weight gradient without the im2col buffer: gw[co][ci][tap] = sum_{frames,pixels} g[co][px] * in[ci][px + tap]
 // (pad 1), the shifted planes built while staging (rows of one image row, W % 8 == 0).  The output is the torch weight
 // layout [Cout][Cin][3][3] (the GEMM on rfn_im2col3x3_f32's buffer gives [Cout][tap][Cin] instead).
+static void select_wgrad_implicit(GemmWgradParams& p, hipStream_t s) {
+    if (p.M > 128 && p.total >= 100000)
+        launch_gemm_wgrad<4, 2, 2, 3, 64, 1>(p, s);   // 256 x 192, 8 waves
+    else
+        launch_gemm_wgrad<2, 2, 2, 2, 64, 1>(p, s);   // 128 x 128
+}
+
 extern "C" int rfn_conv3x3_wgrad_implicit_bf16x3(const float* g, long g_ns, int Cout, const float* in1, long in1_ns, int C1,
                                                  const float* in2, long in2_ns, int C2, float* gw, int F, int H, int W,
                                                  rfn_stream_t stream) {
@@ -305,11 +351,32 @@ extern "C" int rfn_conv3x3_wgrad_implicit_bf16x3(const float* g, long g_ns, int 
     p.a = g; p.a_ns = g_ns; p.M = Cout; p.b = in1; p.b_ns = in1_ns; p.b2 = C2 ? in2 : in1; p.b2_ns = C2 ? in2_ns : in1_ns;
     p.C1 = C1; p.C2 = C2; p.H = H; p.W = W; p.N = 9 * (C1 + C2); p.gw = gw; p.F = F; p.HW = H * W;
     p.total = (long)F * H * W;
-    hipStream_t s = (hipStream_t)stream;
-    if (Cout > 128 && p.total >= 100000)
-        launch_gemm_wgrad<4, 2, 2, 3, 64, 1>(p, s);   // 256 x 192, 8 waves
-    else
-        launch_gemm_wgrad<2, 2, 2, 2, 64, 1>(p, s);   // 128 x 128
+    select_wgrad_implicit(p, (hipStream_t)stream);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// grouped form: G gradients of one shape (per group: g, in1, in2 (ignored when C2 == 0), gw)
+extern "C" int rfn_conv3x3_wgrad_implicit_grouped_bf16x3(const float* const* g, long g_ns, int Cout,
+                                                         const float* const* in1, long in1_ns, int C1,
+                                                         const float* const* in2, long in2_ns, int C2, float* const* gw,
+                                                         int G, int F, int H, int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(g && in1 && gw && G >= 1 && G <= 16 && Cout > 0 && C1 > 0 && C2 >= 0 && (C2 == 0 || in2) && F >= 0, -1);
+    RFN_CHECK_ARG(H > 0 && W > 0 && W % 8 == 0 && g_ns % 4 == 0 && in1_ns % 4 == 0 && (C2 == 0 || in2_ns % 4 == 0), -2);
+    RFN_CHECK_ARG((long)F * H * W < (1L << 31) - 4096, -4);
+    if (F == 0) return 0;
+    GemmWgradParams p;
+    memset(&p, 0, sizeof(p));
+    for (int i = 0; i < G; ++i) {
+        RFN_CHECK_ARG(g[i] && in1[i] && gw[i] && (C2 == 0 || in2[i]), -3);
+        RFN_CHECK_ARG((((uintptr_t)g[i] | (uintptr_t)in1[i] | (uintptr_t)(C2 ? in2[i] : in1[i])) & 15) == 0, -3);
+        p.ga[i] = g[i]; p.gb[i] = in1[i]; p.gb2[i] = C2 ? in2[i] : in1[i]; p.ggw[i] = gw[i];
+    }
+    p.G = G; p.a = g[0]; p.b = in1[0]; p.b2 = p.gb2[0]; p.gw = gw[0];
+    p.a_ns = g_ns; p.M = Cout; p.b_ns = in1_ns; p.b2_ns = C2 ? in2_ns : in1_ns;
+    p.C1 = C1; p.C2 = C2; p.H = H; p.W = W; p.N = 9 * (C1 + C2); p.F = F; p.HW = H * W;
+    p.total = (long)F * H * W;
+    select_wgrad_implicit(p, (hipStream_t)stream);
     RFN_LAUNCH_CHECK();
     return 0;
 }

@@ -50,6 +50,9 @@ SIGNATURES = {
     "rfn_dgrad_small_supported": [_c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_conv3x3_smallcout_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i,
                                      _c_i, _c_s],
+    "rfn_gemm_wgrad_grouped_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i, _c_i, _c_s],
+    "rfn_conv3x3_wgrad_implicit_grouped_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_i, _c_i,
+                                                  _c_i, _c_i, _c_s],
     "rfn_coupling_po_supported": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_coupling_po_packed_bytes": [_c_i, _c_i],
     "rfn_coupling_po_pack": [_c_f, _c_i, _c_s],
@@ -142,6 +145,12 @@ def call(name, *args, meta=None):
         rc = getattr(lib, name)(*args, stream)
     if rc != 0:
         raise RuntimeError("%s failed (code %d): %s" % (name, rc, lib.rfn_last_error().decode()))
+
+
+def ptr_array(tensors, name="tensor"):
+    """host array of device pointers (for the grouped entry points); the caller keeps the tensors alive"""
+    arr = (ctypes.c_void_p * len(tensors))(*[dev(t, name, check_contiguous=False).value for t in tensors])
+    return arr
 
 
 def dev(t, name="tensor", check_contiguous=True):

@@ -388,6 +388,76 @@ def conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena=None):
     return gw.view(3, 3, Cout, Cin).permute(2, 3, 0, 1).contiguous()
 
 
+def gemm_wgrad_grouped(a_list, b_list, M, Nc, arena=None):
+    """G gradients gw[g][M][Nc] = Σ a_g b_g^T of one shape in ONE launch (rfn_gemm_wgrad_grouped_bf16x3)."""
+    G = len(a_list)
+    F_, HW = int(a_list[0].shape[0]), _hw(a_list[0])
+    ans, bns = L.frames(a_list[0], "a")[1], L.frames(b_list[0], "b")[1]
+    gw = _zeros(arena, G, M, Nc, device=a_list[0].device)
+    pa, pb = L.ptr_array(a_list, "a"), L.ptr_array(b_list, "b")
+    pg = L.ptr_array([gw[g] for g in range(G)], "gw")
+    L.call("rfn_gemm_wgrad_grouped_bf16x3", pa, _l(ans), _i(M), pb, _l(bns), _i(Nc), pg, _i(G), _i(F_), _i(HW),
+           meta=("wgrad", "gemm_wgrad_b3_kernel<grouped %s>" % _gemm_wgrad_cfg(M, Nc, F_ * HW),
+                 2.0 * G * F_ * HW * M * Nc, "G%d F%d %dx%d HW%d" % (G, F_, M, Nc, HW),
+                 4.0 * G * (F_ * HW * (M + Nc) + M * Nc)))
+    return gw
+
+
+GROUPED_WGRAD_MAX_PIX = 100000  # below this many pixels a single weight gradient is a latency-class launch
+
+
+def conv2d_wgrad_grouped(in1_list, in2_list, g_list, Cout, ks, arena=None):
+    """the weight gradients of G convolutions of ONE shape (the K steps of a flow level) in one GEMM launch: list of G
+    tensors [Cout, Cin, ks, ks].  Same operand choices as conv2d_wgrad_b3 (the small operand of a 3x3 gradient is
+    expanded per step, the layout fix-up is one copy for all groups)."""
+    G = len(g_list)
+    N, C1, H, W = in1_list[0].shape
+    has2 = in2_list is not None and in2_list[0] is not None
+    C2 = int(in2_list[0].shape[1]) if has2 else 0
+    Cin = C1 + C2
+    dev_ = in1_list[0].device
+    if ks == 1:
+        xs = in1_list if not has2 else [torch.cat((a, b), 1) for a, b in zip(in1_list, in2_list)]
+        gw = gemm_wgrad_grouped(g_list, xs, Cout, Cin, arena)
+        return [gw[i].view(Cout, Cin, 1, 1) for i in range(G)]
+    if Cin <= Cout and W % 8 == 0 and os.environ.get("RFN_WGRAD_IMPLICIT") != "0":
+        gw = _zeros(arena, G, Cout, 9 * Cin, device=dev_)
+        gns, i1ns = L.frames(g_list[0], "g")[1], L.frames(in1_list[0], "in1")[1]
+        i2ns = L.frames(in2_list[0], "in2")[1] if has2 else 0
+        pg, p1 = L.ptr_array(g_list, "g"), L.ptr_array(in1_list, "in1")
+        p2 = L.ptr_array(in2_list, "in2") if has2 else None
+        pw = L.ptr_array([gw[i] for i in range(G)], "gw")
+        L.call("rfn_conv3x3_wgrad_implicit_grouped_bf16x3", pg, _l(gns), _i(Cout), p1, _l(i1ns), _i(C1), p2, _l(i2ns),
+               _i(C2), pw, _i(G), _i(N), _i(H), _i(W),
+               meta=("wgrad", "gemm_wgrad_b3_kernel<grouped implicit>", 2.0 * G * N * H * W * Cout * 9 * Cin,
+                     "G%d F%d %dx%d HW%d implicit3x3" % (G, N, Cout, 9 * Cin, H * W),
+                     4.0 * G * (N * H * W * (Cout + Cin) + Cout * 9 * Cin)))
+        return [gw[i].view(Cout, Cin, 3, 3) for i in range(G)]
+    if Cin <= Cout:
+        x9s = []
+        for i in range(G):
+            i1p, i1ns = L.frames(in1_list[i], "in1")
+            i2p, i2ns = (None, 0) if not has2 else L.frames(in2_list[i], "in2")
+            x9 = torch.empty((N, 9 * Cin, H, W), device=dev_, dtype=torch.float32)
+            L.call("rfn_im2col3x3_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2), L.dev(x9), _i(N), _i(H), _i(W),
+                   meta=_shell("im2col3x3", x9, 10.0 / 9.0))
+            x9s.append(x9)
+        gw = gemm_wgrad_grouped(g_list, x9s, Cout, 9 * Cin, arena)  # [g][co][tap*Cin + ci]
+        gwt = gw.view(G, Cout, 9, Cin).permute(0, 1, 3, 2).reshape(G, Cout, Cin, 3, 3)  # one copy for all groups
+        return [gwt[i] for i in range(G)]
+    xs = in1_list if not has2 else [torch.cat((a, b), 1) for a, b in zip(in1_list, in2_list)]
+    gss = []
+    for i in range(G):
+        gs = torch.empty((N, 9 * Cout, H, W), device=dev_, dtype=torch.float32)
+        gi = g_list[i].contiguous()
+        L.call("rfn_tap_scatter_f32", L.dev(gi), L.dev(gs), _i(N), _i(Cout), _i(H), _i(W),
+               meta=_shell("tap_scatter", gs, 10.0 / 9.0))
+        gss.append(gs)
+    gw = gemm_wgrad_grouped(gss, xs, 9 * Cout, Cin, arena)  # [g][tap*Cout + co][ci]
+    gwt = gw.view(G, 3, 3, Cout, Cin).permute(0, 3, 4, 1, 2).contiguous()
+    return [gwt[i] for i in range(G)]
+
+
 def conv2d_wgrad(in1, in2, g, Cout, ks, arena=None):
     """returns gw [Cout, Cin, ks, ks]"""
     N, C1, H, W = in1.shape
@@ -635,22 +705,24 @@ def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk):
     return h1, h2, o, None
 
 
-def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gcond, acc_cond):
+def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gcond, acc_cond, defer=None):
     """backward of the coupling network from `go` = gradient at conv3's output: returns the parameter gradients
     (gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3); the data gradient of conv1 is ADDED to gz[:, :C/2] and written (acc_cond:
-    added) to gcond."""
+    added) to gcond.  With `defer` (a dict of three lists) the weight gradients are NOT computed: their operands are
+    appended to defer["w1" | "w2" | "w3"] and None is returned in their place (grouped launch by the caller)."""
     N, C, H, W = out.shape
     Ch = C // 2
     Hd = int(w1.shape[0])
     Cc = int(cond.shape[1])
     k1, k2, k3 = int(w1.shape[2]), int(w2.shape[2]), int(w3.shape[2])
-    gw3 = zeros_conv_wgrad(h2, go, C, k3, arena)
+    dfr = defer is not None and bwd_b3() and Hd % 64 == 0 and _hw(h2) % 4 == 0
+    gw3 = None if dfr else zeros_conv_wgrad(h2, go, C, k3, arena)
     w3f = pk[5] if pk[5] is not None else pack_weight(w3, True)
     w2f = pk[3] if pk[3] is not None else pack_weight(w2, True)
     if bwd_b3() and Hd % 64 == 0:
         # data-gradient convs with the backward of the producer's ActNorm+activation fused into their epilogue
         gh2, gn2b, gn2l = conv2d_dgrad_act(go, w3f, h2, _f(n2l), act, Hd, k3, arena)
-        gw2 = conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
+        gw2 = None if dfr else conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
         gh1, gn1b, gn1l = conv2d_dgrad_act(gh2, w2f, h1, _f(n1l), act, Hd, k2, arena)
     else:
         gh2 = conv2d_raw(go, None, w3f, Hd, k3)
@@ -662,7 +734,11 @@ def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gc
         gh1, gn1b, gn1l = conv_epilogue_bwd(h1, gh1, _f(n1l), 1, act, arena=arena)
     z1 = out[:, :Ch]
     has_cond = Cc > 0
-    gw1 = conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
+    gw1 = None if dfr else conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
+    if dfr:
+        defer["w3"].append((h2, go))
+        defer["w2"].append((h1, gh2))
+        defer["w1"].append((z1, cond if has_cond else None, gh1))
     if k1 == 3 and k3 == 3 and smallmap_conv_ok(H, W, Hd, 0, Ch + Cc, N, bwd=True):
         smallmap_conv(gh1, None, smallmap_pack(w1, H, W, True), Ch + Cc, 0, out1=gz[:, :Ch],
                       out2=gcond if has_cond else None, cout_split=Ch, acc1=True, acc2=acc_cond)
@@ -845,10 +921,15 @@ class GlowLevelFn(torch.autograd.Function):
         gz, go, gscale, gshift, gb3, gl3 = _affine_zeros_bwd(outs[Kn - 1], os_[Kn - 1], gout, gdl, scale, scale_shift, l3,
                                                             clamp_type, arena)
         gx = None
+        # latency-class levels (deep levels, small batches): the 3 K weight gradients are computed at the end, K of one
+        # shape per launch (their operands stay alive until then: a few hundred MB at most)
+        defer = ({"w1": [], "w2": [], "w3": []}
+                 if (N * HW <= GROUPED_WGRAD_MAX_PIX and 1 < Kn <= 16 and os.environ.get("RFN_WGRAD_GROUPED") != "0")
+                 else None)
         for k in range(Kn - 1, -1, -1):
             (an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift) = prm[k]
             gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3 = _net_bwd(go, outs[k], cond, h1s[k], h2s[k], w1, n1l, w2, n2l, w3, act,
-                                                             pks[k], arena, gz, gcond, k != Kn - 1)
+                                                             pks[k], arena, gz, gcond, k != Kn - 1, defer)
             base = STEP_NPARAM * k
             grads[base + 2:base + 13] = [gw1, gn1b.view(1, -1, 1, 1), gn1l.view(n1l.shape), gw2, gn2b.view(1, -1, 1, 1),
                                          gn2l.view(n2l.shape), gw3, gb3, gl3.view(l3.shape),
@@ -885,6 +966,18 @@ class GlowLevelFn(torch.autograd.Function):
                    L.dev(hold[2]), gznp, _l(gznns), gonp, _l(gonns), L.dev(gscale), L.dev(gshift), L.dev(gb3),
                    L.dev(gl3), _i(clamp_type), _i(1), _i(N), _i(C), _i(HW), meta=_shell("glow_shell_bwd", xin, 5.5))
             gz, go = gzn, gon
+        if defer is not None and defer["w2"]:
+            # entries were appended for k = Kn-1 .. 0
+            order = list(range(Kn - 1, -1, -1))
+            Hd_ = int(prm[0][2].shape[0])
+            g1 = conv2d_wgrad_grouped([t[0] for t in defer["w1"]],
+                                      None if defer["w1"][0][1] is None else [t[1] for t in defer["w1"]],
+                                      [t[2] for t in defer["w1"]], Hd_, k1, arena)
+            g2 = conv2d_wgrad_grouped([t[0] for t in defer["w2"]], None, [t[1] for t in defer["w2"]], Hd_, k2, arena)
+            g3 = conv2d_wgrad_grouped([t[0] for t in defer["w3"]], None, [t[1] for t in defer["w3"]], C, k3, arena)
+            for i, k in enumerate(order):
+                base = STEP_NPARAM * k
+                grads[base + 2], grads[base + 5], grads[base + 8] = g1[i], g2[i], g3[i]
         return (gx, gcond, gWst, None, None, None) + tuple(grads)
 
 
