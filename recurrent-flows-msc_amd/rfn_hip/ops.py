@@ -406,10 +406,11 @@ def gemm_wgrad_grouped(a_list, b_list, M, Nc, arena=None):
 GROUPED_WGRAD_MAX_PIX = 100000  # below this many pixels a single weight gradient is a latency-class launch
 
 
-def conv2d_wgrad_grouped(in1_list, in2_list, g_list, Cout, ks, arena=None):
+def conv2d_wgrad_grouped(in1_list, in2_list, g_list, Cout, ks, arena=None, g_stacked=None):
     """the weight gradients of G convolutions of ONE shape (the K steps of a flow level) in one GEMM launch: list of G
     tensors [Cout, Cin, ks, ks].  Same operand choices as conv2d_wgrad_b3 (the small operand of a 3x3 gradient is
-    expanded per step, the layout fix-up is one copy for all groups)."""
+    expanded per step -- in one launch when the gradients are the slices of `g_stacked` -- and the layout fix-up is one
+    copy for all groups)."""
     G = len(g_list)
     N, C1, H, W = in1_list[0].shape
     has2 = in2_list is not None and in2_list[0] is not None
@@ -447,12 +448,19 @@ def conv2d_wgrad_grouped(in1_list, in2_list, g_list, Cout, ks, arena=None):
         return [gwt[i] for i in range(G)]
     xs = in1_list if not has2 else [torch.cat((a, b), 1) for a, b in zip(in1_list, in2_list)]
     gss = []
-    for i in range(G):
-        gs = torch.empty((N, 9 * Cout, H, W), device=dev_, dtype=torch.float32)
-        gi = g_list[i].contiguous()
-        L.call("rfn_tap_scatter_f32", L.dev(gi), L.dev(gs), _i(N), _i(Cout), _i(H), _i(W),
-               meta=_shell("tap_scatter", gs, 10.0 / 9.0))
-        gss.append(gs)
+    if g_stacked is not None and g_stacked.is_contiguous() and tuple(g_stacked.shape) == (G, N, Cout, H, W):
+        # the G gradients are slices of one [G, N, Cout, H, W] buffer (in list order): one scatter launch over G*N frames
+        gs_all = torch.empty((G, N, 9 * Cout, H, W), device=dev_, dtype=torch.float32)
+        L.call("rfn_tap_scatter_f32", L.dev(g_stacked), L.dev(gs_all), _i(G * N), _i(Cout), _i(H), _i(W),
+               meta=_shell("tap_scatter", gs_all, 10.0 / 9.0))
+        gss = [gs_all[i] for i in range(G)]
+    else:
+        for i in range(G):
+            gs = torch.empty((N, 9 * Cout, H, W), device=dev_, dtype=torch.float32)
+            gi = g_list[i].contiguous()
+            L.call("rfn_tap_scatter_f32", L.dev(gi), L.dev(gs), _i(N), _i(Cout), _i(H), _i(W),
+                   meta=_shell("tap_scatter", gs, 10.0 / 9.0))
+            gss.append(gs)
     gw = gemm_wgrad_grouped(gss, xs, 9 * Cout, Cin, arena)  # [g][tap*Cout + co][ci]
     gwt = gw.view(G, 3, 3, Cout, Cin).permute(0, 3, 4, 1, 2).contiguous()
     return [gwt[i] for i in range(G)]
@@ -758,12 +766,13 @@ def _net_arena_numel(C, Cc, Hd, k1, k2, k3):
             + max(k3 * k3 * C * Hd, 9 * C * Hd) + C * C + 2 * C + 64)
 
 
-def _affine_zeros_bwd(out, o, gout, gdl, scale, scale_shift, l3, clamp_type, arena):
+def _affine_zeros_bwd(out, o, gout, gdl, scale, scale_shift, l3, clamp_type, arena, go=None):
     """rfn_affine_zeros_bwd_f32: returns (gz, go, gscale, gshift, gb3, gl3)"""
     N, C, H, W = out.shape
     Ch, HW = C // 2, H * W
     gz = torch.empty_like(gout)
-    go = torch.empty_like(o)
+    if go is None:
+        go = torch.empty_like(o)
     gscale = gshift = None
     if clamp_type == 0:
         gscale = arena.take(Ch)
@@ -918,8 +927,12 @@ class GlowLevelFn(torch.autograd.Function):
         grads = [None] * nf
         # last step: stand-alone coupling backward; earlier steps get theirs from the fused shell launch below
         (_, _, _, _, _, _, _, _, _, _, l3, scale, scale_shift) = prm[Kn - 1]
+        # (with deferred weight gradients the K conv3-output gradients live in one buffer: one tap-scatter for all)
+        go_all = (torch.empty((Kn,) + tuple(os_[0].shape), device=x.device, dtype=torch.float32)
+                  if (N * HW <= GROUPED_WGRAD_MAX_PIX and 1 < Kn <= 16 and os.environ.get("RFN_WGRAD_GROUPED") != "0")
+                  else None)
         gz, go, gscale, gshift, gb3, gl3 = _affine_zeros_bwd(outs[Kn - 1], os_[Kn - 1], gout, gdl, scale, scale_shift, l3,
-                                                            clamp_type, arena)
+                                                            clamp_type, arena, None if go_all is None else go_all[Kn - 1])
         gx = None
         # latency-class levels (deep levels, small batches): the 3 K weight gradients are computed at the end, K of one
         # shape per launch (their operands stay alive until then: a few hundred MB at most)
@@ -951,7 +964,7 @@ class GlowLevelFn(torch.autograd.Function):
             (_, _, _, _, _, _, _, _, _, _, l3p, scalep, shiftp) = prm[k - 1]
             xin, op_ = outs[k - 1], os_[k - 1]
             gzn = torch.empty_like(gz)
-            gon = torch.empty_like(op_)
+            gon = torch.empty_like(op_) if go_all is None else go_all[k - 1]
             gscale = gshift = None
             if clamp_type == 0:
                 gscale, gshift = arena.take(Ch), arena.take(Ch)
@@ -967,17 +980,19 @@ class GlowLevelFn(torch.autograd.Function):
                    L.dev(gl3), _i(clamp_type), _i(1), _i(N), _i(C), _i(HW), meta=_shell("glow_shell_bwd", xin, 5.5))
             gz, go = gzn, gon
         if defer is not None and defer["w2"]:
-            # entries were appended for k = Kn-1 .. 0
-            order = list(range(Kn - 1, -1, -1))
+            # entries were appended for k = Kn-1 .. 0: back to step order
+            for key in ("w1", "w2", "w3"):
+                defer[key].reverse()
             Hd_ = int(prm[0][2].shape[0])
             g1 = conv2d_wgrad_grouped([t[0] for t in defer["w1"]],
                                       None if defer["w1"][0][1] is None else [t[1] for t in defer["w1"]],
                                       [t[2] for t in defer["w1"]], Hd_, k1, arena)
             g2 = conv2d_wgrad_grouped([t[0] for t in defer["w2"]], None, [t[1] for t in defer["w2"]], Hd_, k2, arena)
-            g3 = conv2d_wgrad_grouped([t[0] for t in defer["w3"]], None, [t[1] for t in defer["w3"]], C, k3, arena)
-            for i, k in enumerate(order):
+            g3 = conv2d_wgrad_grouped([t[0] for t in defer["w3"]], None, [t[1] for t in defer["w3"]], C, k3, arena,
+                                      g_stacked=go_all)
+            for k in range(Kn):
                 base = STEP_NPARAM * k
-                grads[base + 2], grads[base + 5], grads[base + 8] = g1[i], g2[i], g3[i]
+                grads[base + 2], grads[base + 5], grads[base + 8] = g1[k], g2[k], g3[k]
         return (gx, gcond, gWst, None, None, None) + tuple(grads)
 
 
