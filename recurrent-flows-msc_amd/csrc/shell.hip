@@ -1390,12 +1390,24 @@ __global__ __launch_bounds__(256) void stepbn_stats_kernel(const float* __restri
     const long fs = (long)C * HW;
     const float K = base[0];
     float a = 0.f, v = 0.f;
-    for (int b = blockIdx.y; b < B; b += gridDim.y) {
-        const float* row = base + b * fs;
-        for (int p = threadIdx.x; p < HW; p += 256) {
-            const float d = row[p] - K;
-            a += d;
-            v = fmaf(d, d, v);
+    if ((HW & 3) == 0 && (((uintptr_t)x) & 15) == 0) {  // 16-byte loads (frames and channel planes stay aligned)
+        // (frame, pixel quad) pairs of this block flattened over the threads: small maps keep all 256 lanes busy
+        const int HW4 = HW >> 2, nb = (B - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+        for (int idx = threadIdx.x; idx < nb * HW4; idx += 256) {
+            const int bi = idx / HW4, p = idx - bi * HW4;
+            const float4 q = reinterpret_cast<const float4*>(base + (blockIdx.y + (long)bi * gridDim.y) * fs)[p];
+            const float d0 = q.x - K, d1 = q.y - K, d2 = q.z - K, d3 = q.w - K;
+            a += (d0 + d1) + (d2 + d3);
+            v = fmaf(d0, d0, fmaf(d1, d1, fmaf(d2, d2, fmaf(d3, d3, v))));
+        }
+    } else {
+        for (int b = blockIdx.y; b < B; b += gridDim.y) {
+            const float* row = base + b * fs;
+            for (int p = threadIdx.x; p < HW; p += 256) {
+                const float d = row[p] - K;
+                a += d;
+                v = fmaf(d, d, v);
+            }
         }
     }
     const float ta = block_sum_256(a, sm);
@@ -1463,13 +1475,30 @@ __global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __r
     const float m = mean[blockIdx.x], rstd = rsqrtf(var[blockIdx.x] + eps);
     const float ga = gamma ? gamma[c] : 1.f, be = gamma ? beta[c] : 0.f;
     float a = 0.f, ax = 0.f;
-    for (int b = blockIdx.y; b < B; b += gridDim.y) {
-        const long e0 = off + b * fs;
-        for (int p = threadIdx.x; p < HW; p += 256) {
-            const float xh = (x[e0 + p] - m) * rstd;
-            const float gp = g[e0 + p] * stepbn_dact(xh * ga + be, act, slope);
-            a += gp;
-            ax = fmaf(gp, xh, ax);
+    if ((HW & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)g)) & 15) == 0) {  // 16-byte loads
+        const int HW4 = HW >> 2, nb = (B - (int)blockIdx.y + (int)gridDim.y - 1) / (int)gridDim.y;
+        for (int idx = threadIdx.x; idx < nb * HW4; idx += 256) {
+            const int bi = idx / HW4, p = idx - bi * HW4;
+            const long e0 = off + (blockIdx.y + (long)bi * gridDim.y) * fs;
+            const float4 xq = reinterpret_cast<const float4*>(x + e0)[p], gq = reinterpret_cast<const float4*>(g + e0)[p];
+            const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, gv[4] = {gq.x, gq.y, gq.z, gq.w};
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const float xh = (xv[i] - m) * rstd;
+                const float gp = gv[i] * stepbn_dact(xh * ga + be, act, slope);
+                a += gp;
+                ax = fmaf(gp, xh, ax);
+            }
+        }
+    } else {
+        for (int b = blockIdx.y; b < B; b += gridDim.y) {
+            const long e0 = off + b * fs;
+            for (int p = threadIdx.x; p < HW; p += 256) {
+                const float xh = (x[e0 + p] - m) * rstd;
+                const float gp = g[e0 + p] * stepbn_dact(xh * ga + be, act, slope);
+                a += gp;
+                ax = fmaf(gp, xh, ax);
+            }
         }
     }
     const float ta = block_sum_256(a, sm);
