@@ -340,6 +340,41 @@ def test_fused_shell_tail_fwd_bwd(K, clamp, N, C, H, W):
         assert relerr(gsh, sd["scale_shift"].grad.reshape(-1)) < 1e-4
 
 
+@pytest.mark.parametrize("clamp", ["realnvp", "glow", "softclamp", "none"])
+def test_standalone_affine_backward_matches_fused_kernel(K, clamp):
+    """rfn_affine_coupling_bwd_f32 (the stand-alone coupling backward of the C ABI; the host path uses the fused
+    rfn_affine_zeros_bwd_f32) gives the same gz2, go and clamp-parameter gradients as the fused kernel with Conv2dZeros
+    logs = 0 (exp(0) = 1: gpre == go), which test_fused_shell_tail_fwd_bwd checks against autograd."""
+    from rfn_hip import lib as L
+    import ctypes
+    g = torch.Generator().manual_seed(23)
+    N, C, H, W = 3, 6, 4, 5
+    Ch, HW, st = C // 2, H * W, C * H * W
+    zout, o, gout = (cu(torch.randn(N, C, H, W, generator=g)) for _ in range(3))
+    gld = cu(torch.randn(N, generator=g))
+    sc, sh = cu(torch.randn(Ch, generator=g) * 0.5), cu(torch.randn(Ch, generator=g) * 0.1)
+    rn = clamp == "realnvp"
+    ct, _l, _i = K.CLAMP[clamp], ctypes.c_long, ctypes.c_int
+    gz_a = gout.clone()
+    go_a = torch.empty_like(o)
+    acc_a = torch.zeros(2, Ch, device="cuda")
+    L.call("rfn_affine_coupling_bwd_f32", L.dev(zout), _l(st), L.dev(o), _l(st), L.dev(gout), _l(st), L.dev(gld),
+           L.dev(sc), L.dev(sh), L.dev(gz_a), _l(st), L.dev(go_a), _l(st), L.dev(acc_a[0]) if rn else None,
+           L.dev(acc_a[1]) if rn else None, _i(ct), _i(N), _i(C), _i(HW))
+    gz_b, go_b = torch.empty_like(gout), torch.empty_like(o)
+    acc_b = torch.zeros(2, Ch, device="cuda")
+    junk = torch.zeros(2, C, device="cuda")
+    l3 = torch.zeros(C, device="cuda")
+    L.call("rfn_affine_zeros_bwd_f32", L.dev(zout), _l(st), L.dev(o), _l(st), L.dev(gout), _l(st), L.dev(gld), L.dev(sc),
+           L.dev(sh), L.dev(l3), L.dev(gz_b), _l(st), L.dev(go_b), _l(st), L.dev(acc_b[0]) if rn else None,
+           L.dev(acc_b[1]) if rn else None, L.dev(junk[0]), L.dev(junk[1]), _i(ct), _i(N), _i(C), _i(HW))
+    assert torch.equal(gz_a[:, :Ch], gout[:, :Ch])      # first half untouched by the stand-alone kernel
+    assert relerr(gz_a[:, Ch:], gz_b[:, Ch:]) < 1e-6 and torch.equal(gz_b[:, :Ch], gout[:, :Ch])
+    assert relerr(go_a, go_b) < 1e-6
+    if rn:
+        assert relerr(acc_a, acc_b) < 1e-5
+
+
 @pytest.mark.parametrize("layout,std_mode", [(0, 0), (0, 1), (1, 1), (1, 0)])
 def test_gauss_logp_fwd_bwd_sample(K, layout, std_mode):
     g = torch.Generator().manual_seed(6)
