@@ -576,6 +576,8 @@ def test_canonical_rfn_loss_vs_oracle_T10(conv_precision):
     'mixed' (the shipped arithmetic) and 'f32' must hold the budget everywhere; all-'bf16x3' only on the
     well-conditioned model -- two bf16 pieces per operand are 16 significant bits (tools/precision_study.py) and measure
     1e-4..5e-4 on the ill-conditioned one, which is why the forward pass does not use them.
+    The GPU figure is the median of three evaluations of the same weights (bench.parity_check): in the ill-conditioned
+    case the run-dependent order of the split-K float atomics alone moves bits/dim by 1e-5..8e-5, fp32 kernels included.
     This is the gate bench.py uses to choose its headline run."""
     import bench
     r = bench.parity_check(torch.device("cuda"), T=10, scales=(0.003, 0.01, 0.1))
