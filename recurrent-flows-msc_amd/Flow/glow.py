@@ -85,8 +85,9 @@ class GlowStep(nn.Module):
         for m in (aff.net[0].norm_type, aff.net[2].norm_type):
             if m.needs_init():
                 m.mark_initialized()
-        Winv, _ = self.invconv.get_weight(x, reverse=True)
-        out, dl = K.GlowStepRevFn.apply(x, condition, Winv, an.bias, an.logs, *aff.nn_params(), act, clamp)
+        # `Wm` (optional, reverse): the inverse matrix from the caller's generation cache; `packs`: its packed-weight dict
+        Winv = Wm if Wm is not None else self.invconv.get_weight(x, reverse=True)[0]
+        out, dl = K.GlowStepRevFn.apply(x, condition, Winv, an.bias, an.logs, *aff.nn_params(), act, clamp, packs)
         if logdet is not None:
             logdet = logdet + dl - self._param_logdet(x)
         return out, logdet
@@ -271,10 +272,38 @@ class ListGlow(nn.Module):
         return z, logdet
 
     # ---- z -> x ------------------------------------------------------------------------------------------
+    def _reverse_cache(self):
+        """{GlowStep: (U^-1 L^-1 P^T, packed-weight dict)} for generation, valid while no parameter changes (keyed by
+        the parameters' version counters).  Autoregressive generation calls g() once per frame with unchanged weights:
+        the reference rebuilds three matrix inverses per step and frame (glow_modules.py:198-203); here the inverses of
+        a level are two batched triangular solves, done once, and the weight packs are kept."""
+        key = tuple((p._version, p.data_ptr()) for p in self.parameters())
+        cache = getattr(self, "_rev_cache", None)
+        if cache is not None and cache[0] == key:
+            return cache[1]
+        table = {}
+        with torch.no_grad():
+            for _, steps, _ in self._level_steps():
+                ics = [s.invconv for s in steps]
+                if all(ic.LU_decomposed for ic in ics) and not any(s.flow_norm == "batchnorm" for s in steps):
+                    l_mask, eye = ics[0].l_mask, ics[0].eye
+                    Lm = torch.stack([ic.lower for ic in ics]) * l_mask + eye
+                    U = torch.stack([ic.upper for ic in ics]) * l_mask.t() + torch.diag_embed(
+                        torch.stack([ic.sign_s for ic in ics]) * torch.exp(torch.stack([ic.log_s for ic in ics])))
+                    Pt = torch.stack([ic.p for ic in ics]).transpose(1, 2)
+                    Winv = torch.linalg.solve_triangular(
+                        U, torch.linalg.solve_triangular(Lm, Pt, upper=False, unitriangular=True), upper=True)
+                    for i, s_ in enumerate(steps):
+                        table[s_] = (Winv[i].contiguous(), {})
+        self._rev_cache = (key, table)
+        return table
+
     def g(self, z, condition, logdet, temperature, eps_list=None):
         """Flow/glow.py:90-102.  `eps_list` (optional) pins the N(0,1) draws of the Split2d layers, coarsest first."""
         x, l = z, len(condition) - 1
         eps_list = list(eps_list) if eps_list is not None else None
+        cache = (self._reverse_cache()
+                 if (x.is_cuda and not torch.is_grad_enabled() and os.environ.get("RFN_GEN_CACHE") != "0") else {})
         for step in reversed(self.glow_frame):
             if isinstance(step, Squeeze2d):
                 x = step(x, undo_squeeze=True)
@@ -283,7 +312,8 @@ class ListGlow(nn.Module):
                 e = eps_list.pop(0) if eps_list else None
                 x, logdet = step(x, condition[l], logdet=logdet, reverse=True, temperature=temperature, eps=e)
             else:
-                x, logdet = step(x, condition[l], logdet=logdet, reverse=True)
+                Winv, pk = cache.get(step, (None, None))
+                x, logdet = step(x, condition[l], logdet=logdet, reverse=True, Wm=Winv, packs=pk)
         return x, logdet
 
     def uniform_binning_correction(self, x, noise=None):

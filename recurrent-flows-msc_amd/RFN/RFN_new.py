@@ -10,6 +10,8 @@ MI355X-first restructuring of `loss` (same mathematics, RFN/RFN_new.py:116-247):
      (`frame = (t-1)·B + b`), so every kernel launch carries the whole sequence batch.
 Data dependent ActNorm initialisation uses the first B frames (t = 1) exactly like the reference's first call.
 """
+import os
+
 import torch
 import torch.nn as nn
 
@@ -237,6 +239,69 @@ class RFN(nn.Module):
 
     # ------------------------------------------------------------------------------------------------ generation
     # `draws` (optional, tests): the noise in the reference's draw order, see each method.
+    def _gen_step(self, prediction, hprev, cprev, zprev, eps, kl_temp):
+        """one autoregressive generation step (RFN_new.py:331-356 / :480-491): frame t-1 -> frame t.
+        eps: [prior eps, flow base eps, Split2d eps (coarsest first) ...].  Returns (frame, ht, ct, zt)."""
+        eps = list(eps)
+        take = lambda ref=None: eps.pop(0)
+        condition_list = self.extractor(prediction)
+        _, ht, ct = self.lstm(self._last(condition_list).unsqueeze(1), hprev, cprev)
+        pm, ps = self.prior(torch.cat((ht, zprev), dim=1))
+        zt = pm + ps * kl_temp * take(pm)
+        hz = torch.cat((ht, zt), dim=1)
+        fc = self._flow_conditions(hz, condition_list)
+        frame = self._flow_sample(fc, hz, take, True)
+        return frame, ht, ct, zt
+
+    def _gen_eps_shapes(self, B):
+        """shapes of the draws of one generation step: prior eps, base eps, Split2d eps list (coarsest first)"""
+        hu, wu = self.z_0.shape[2], self.z_0.shape[3]
+        shapes = [(B, self.z_dim, hu, wu)]
+        c, h, w = self.x_dim[1], self.x_dim[2], self.x_dim[3]
+        split = []
+        for l in range(self.L):
+            c, h, w = c * 4, h // 2, w // 2
+            if l < self.L - 1:
+                c = c // 2
+                split.append((B, c, h, w))
+        shapes.append((B, c, h, w))          # base distribution = what is left after the last level
+        return shapes + split[::-1]
+
+    def _gen_step_graphed(self, prediction, hprev, cprev, zprev, kl_temp):
+        """_gen_step with fresh N(0,1) draws, replayed from a hipGraph: generation is one frame at a time, a few hundred
+        launches of a few microseconds each, i.e. bound by the host's launch rate when launched eagerly (38 ms per frame at
+        B = 32 against ~6 ms of GPU work).  The graph is rebuilt whenever a parameter changed (the inverse matrices and
+        weight packs of ListGlow._reverse_cache are baked into it) or the shapes do; the draws are inputs of the graph."""
+        import rfn_hip
+        dev = prediction.device
+        eps = [torch.randn(sh, device=dev) for sh in self._gen_eps_shapes(prediction.shape[0])]
+        args = [prediction, hprev, cprev, zprev] + eps
+        ok = (dev.type == "cuda" and rfn_hip.graph_capture_safe() and not self.training
+              and os.environ.get("RFN_GEN_GRAPH", "1") != "0")
+        if not ok:
+            return self._gen_step(prediction, hprev, cprev, zprev, eps, kl_temp)
+        key = (tuple((p._version, p.data_ptr()) for p in self.parameters()), tuple(tuple(a.shape) for a in args),
+               float(kl_temp), float(self.temperature))
+        g = getattr(self, "_gen_graph", None)
+        if g is None or g[0] != key:
+            static_in = [a.clone() for a in args]
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):
+                for _ in range(2):  # warm-up on the capture path (lazy per-stream state, generation cache, MIOpen)
+                    self._gen_step(*static_in[:4], static_in[4:], kl_temp)
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                static_out = self._gen_step(*static_in[:4], static_in[4:], kl_temp)
+            g = self._gen_graph = (key, graph, static_in, static_out)
+            self._gen_graph_builds = getattr(self, "_gen_graph_builds", 0) + 1
+        _, graph, static_in, static_out = g
+        for s_, a in zip(static_in, args):
+            s_.copy_(a)
+        graph.replay()
+        return tuple(o.clone() for o in static_out)
+
     def _flow_sample(self, fc, hz, take, pinned, z=None):
         """flow.sample with pinned draws: base eps (only when z is None), then the Split2d eps list, coarsest first"""
         eb = take() if (pinned and z is None) else None
@@ -266,18 +331,17 @@ class RFN(nn.Module):
                 zprev = prior_mean + prior_std * self.kl_temperature * take(prior_mean)
                 zxprev = enc_mean + enc_std * take(enc_mean)
             true_x = x[:, :n_conditions].transpose(0, 1).detach().cpu().clone()
-            predictions = torch.zeros((n_predictions, *x[:, 0].shape))
+            frames = []  # kept on the device: ONE device-to-host copy at the end instead of a sync per frame
             prediction = x[:, n_conditions - 1]
             for i in range(n_predictions):
-                condition_list = self.extractor(prediction)
-                _, ht, ct = self.lstm(self._last(condition_list).unsqueeze(1), hprev, cprev)
-                pm, ps = self.prior(torch.cat((ht, zprev), dim=1))
-                zt = pm + ps * self.kl_temperature * take(pm)
-                hz = torch.cat((ht, zt), dim=1)
-                fc = self._flow_conditions(hz, condition_list)
-                prediction = self._flow_sample(fc, hz, take, dr is not None)
-                predictions[i] = prediction.detach().cpu()
+                if dr is None:
+                    prediction, ht, ct, zt = self._gen_step_graphed(prediction, hprev, cprev, zprev, self.kl_temperature)
+                else:
+                    eps = [take() for _ in range(self.L + 1)]
+                    prediction, ht, ct, zt = self._gen_step(prediction, hprev, cprev, zprev, eps, self.kl_temperature)
+                frames.append(prediction.detach())
                 hprev, cprev, zprev = ht, ct, zt
+            predictions = (torch.stack(frames, 0).cpu() if frames else torch.zeros((0, *x[:, 0].shape)))
         return true_x, predictions
 
     def reconstruct(self, x, draws=None):
@@ -289,8 +353,9 @@ class RFN(nn.Module):
             take, dr = self._taker(draws, x.device)
             T = x.shape[1]
             hprev, cprev, aprev, caprev, _, zxprev, _, _, _ = self.get_inits()
-            recons = torch.zeros((T, *x[:, 0].shape))
-            recons_flow = torch.zeros((T, *x[:, 0].shape))
+            # results stay on the device until the end: a pageable device-to-host copy per frame stalls the launch stream
+            recons = torch.zeros((T, *x[:, 0].shape), device=x.device)
+            recons_flow = torch.zeros((T, *x[:, 0].shape), device=x.device)
             feats = [self.extractor(x[:, i]) for i in range(T)]
             store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
             for i in range(1, T):
@@ -306,10 +371,10 @@ class RFN(nn.Module):
                 hz = torch.cat((ht, zxt), dim=1)
                 fc = self._flow_conditions(hz, feats[i - 1])
                 z, _ = self.flow.log_prob(x[:, i], fc, hz, 0.0, take() if dr is not None else None)
-                recons_flow[i] = self._flow_sample(fc, hz, take, dr is not None, z=z).cpu()
-                recons[i] = self._flow_sample(fc, hz, take, dr is not None).cpu()
+                recons_flow[i] = self._flow_sample(fc, hz, take, dr is not None, z=z)
+                recons[i] = self._flow_sample(fc, hz, take, dr is not None)
                 zxprev = zxt
-        return recons, recons_flow
+        return recons.cpu(), recons_flow.cpu()
 
     def sample(self, x, n_samples, draws=None):
         """RFN/RFN_new.py:453-494 — unconditional roll-out from the first frame.
@@ -318,18 +383,17 @@ class RFN(nn.Module):
         with torch.no_grad():
             take, dr = self._taker(draws, x.device)
             hprev, cprev, _, _, zprev, _, _, _, _ = self.get_inits()
-            samples = torch.zeros((n_samples, *x[:, 0].shape))
-            condition_list = self.extractor(x[:, 0])
+            frames = []
+            sample = x[:, 0]
             for i in range(n_samples):
-                _, ht, ct = self.lstm(self._last(condition_list).unsqueeze(1), hprev, cprev)
-                pm, ps = self.prior(torch.cat((ht, zprev), dim=1))
-                zt = pm + ps * take(pm)
-                hz = torch.cat((ht, zt), dim=1)
-                fc = self._flow_conditions(hz, condition_list)
-                sample = self._flow_sample(fc, hz, take, dr is not None)
-                samples[i] = sample.cpu()
+                if dr is None:
+                    sample, ht, ct, zt = self._gen_step_graphed(sample, hprev, cprev, zprev, 1.0)
+                else:
+                    eps = [take() for _ in range(self.L + 1)]
+                    sample, ht, ct, zt = self._gen_step(sample, hprev, cprev, zprev, eps, 1.0)
+                frames.append(sample)
                 zprev, hprev, cprev = zt, ht, ct
-                condition_list = self.extractor(sample)
+            samples = torch.stack(frames, 0).cpu() if frames else torch.zeros((0, *x[:, 0].shape))
         return samples
 
     # ------------------------------------------------------------------------------------------------ analyses
@@ -376,10 +440,10 @@ class RFN(nn.Module):
             hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
             feats = [self.extractor(x[:, i]) for i in range(T)]
             store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
-            kld = torch.zeros((T, B))
-            nlls = torch.zeros((2, T, B))
-            recons = torch.zeros((2, T, *x[:, 0].shape)) if sample else 0
-            recons_flow = torch.zeros((2, T, *x[:, 0].shape)) if sample else 0
+            kld = torch.zeros((T, B), device=x.device)
+            nlls = torch.zeros((2, T, B), device=x.device)
+            recons = torch.zeros((2, T, *x[:, 0].shape), device=x.device) if sample else 0
+            recons_flow = torch.zeros((2, T, *x[:, 0].shape), device=x.device) if sample else 0
             nsplit = self.L - 1
             for i in range(1, T):
                 zt, zxt, pm, ps, em, es = self._post_prior_step(i, store_ht, store_at, feats, zprev, zxprev, take)
@@ -388,18 +452,20 @@ class RFN(nn.Module):
                     hz = torch.cat((ht, zk), dim=1)
                     fc = self._flow_conditions(hz, feats[i - 1])
                     b, nll = self.flow.log_prob(x[:, i], fc, hz, 0.0, take() if dr is not None else None)
-                    nlls[count, i] = nll.cpu()
+                    nlls[count, i] = nll
                     if sample:
                         e1 = [take() for _ in range(nsplit)] if dr is not None else None
                         rf = self.flow.sample(b, fc, hz, temperature=self.temperature, eps_list=e1)
                         eb = take() if dr is not None else None
                         e2 = [take() for _ in range(nsplit)] if dr is not None else None
                         rs = self.flow.sample(None, fc, hz, temperature=self.temperature, eps_base=eb, eps_list=e2)
-                        recons[count, i] = rs.cpu()
-                        recons_flow[count, i] = rf.cpu()
+                        recons[count, i] = rs
+                        recons_flow[count, i] = rf
                 zprev, zxprev = zt, zxt
-                kld[i] = kl_normal(em, es, pm, ps).sum([1, 2, 3]).cpu()
-        return recons, recons_flow, kld, nlls
+                kld[i] = kl_normal(em, es, pm, ps).sum([1, 2, 3])
+        if sample:
+            recons, recons_flow = recons.cpu(), recons_flow.cpu()
+        return recons, recons_flow, kld.cpu(), nlls.cpu()
 
     def probability_future(self, x, n_conditions, draws=None):
         """RFN/RFN_new.py:590-685 -- NLL of the frames after n_conditions conditioning frames under the LAST conditioned
@@ -412,7 +478,7 @@ class RFN(nn.Module):
             B, T = x.shape[0], x.shape[1]
             take, dr = self._taker(draws, x.device)
             hprev, cprev, aprev, caprev, zprev, zxprev, _, _, _ = self.get_inits()
-            out = torch.zeros((B, 2, T - n_conditions - 1))
+            out = torch.zeros((B, 2, T - n_conditions - 1), device=x.device)
             feats = [self.extractor(x[:, i]) for i in range(n_conditions)]
             store_ht, store_at, _, _ = self._deterministic_states(feats, n_conditions, hprev, cprev, aprev, caprev)
             zt = zxt = None
@@ -425,8 +491,8 @@ class RFN(nn.Module):
                     hz = torch.cat((ht, zk), dim=1)
                     fc = self._flow_conditions(hz, feats[n_conditions - 2])
                     _, nll = self.flow.log_prob(x[:, i], fc, hz, 0.0, take() if dr is not None else None)
-                    out[:, count, i - n_conditions - 1] = nll.cpu()
-        return out
+                    out[:, count, i - n_conditions - 1] = nll
+        return out.cpu()
 
     def param_analysis(self, x, n_predictions, n_conditions, draws=None):
         """RFN/RFN_new.py:496-588 -- prior / posterior / flow-base parameters along the sequence and one flow sample per
@@ -442,22 +508,24 @@ class RFN(nn.Module):
             feats = [self.extractor(x[:, i]) for i in range(T)]
             store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
             zs = tuple(zprev.shape[1:])
-            mu_p, std_p = torch.zeros((T - 1, B) + zs), torch.zeros((T - 1, B) + zs)
-            mu_q, std_q = torch.zeros((T - 1, B) + zs), torch.zeros((T - 1, B) + zs)
+            dv = x.device
+            mu_p, std_p = torch.zeros((T - 1, B) + zs, device=dv), torch.zeros((T - 1, B) + zs, device=dv)
+            mu_q, std_q = torch.zeros((T - 1, B) + zs, device=dv), torch.zeros((T - 1, B) + zs, device=dv)
             mu_flow, std_flow = [], []
-            predictions = torch.zeros((B, T, *x.shape[2:]))
+            predictions = torch.zeros((B, T, *x.shape[2:]), device=dv)
             nsplit = self.L - 1
             for i in range(1, T):
                 zt, zxt, pm, ps, em, es = self._post_prior_step(i, store_ht, store_at, feats, zprev, zxprev, take)
-                mu_p[i - 1], std_p[i - 1], mu_q[i - 1], std_q[i - 1] = pm.cpu(), ps.cpu(), em.cpu(), es.cpu()
+                mu_p[i - 1], std_p[i - 1], mu_q[i - 1], std_q[i - 1] = pm, ps, em, es
                 ht = store_ht[i - 1]
                 fc = self._flow_conditions(torch.cat((ht, zxt), dim=1), feats[i - 1])
                 base = torch.cat((ht, zt), dim=1)
                 eb = take() if dr is not None else None
                 el = [take() for _ in range(nsplit)] if dr is not None else None
                 pred, params = self.flow.sample(None, fc, base, 1.0, eval_params=True, eps_base=eb, eps_list=el)
-                mu_flow.append(params[0].cpu())
-                std_flow.append(params[1].cpu())
-                predictions[:, i] = pred.cpu()
+                mu_flow.append(params[0])
+                std_flow.append(params[1])
+                predictions[:, i] = pred
                 zprev, zxprev = zt, zxt
-        return mu_p, std_p, mu_q, std_q, torch.stack(mu_flow), torch.stack(std_flow), predictions
+        return (mu_p.cpu(), std_p.cpu(), mu_q.cpu(), std_q.cpu(), torch.stack(mu_flow).cpu(), torch.stack(std_flow).cpu(),
+                predictions.cpu())

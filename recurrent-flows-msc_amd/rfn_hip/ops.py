@@ -1001,7 +1001,9 @@ class GlowStepRevFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, cond, Winv, an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift,
-                act, clamp_type):
+                act, clamp_type, pkcache=None):
+        """`pkcache` (optional dict, owned by the caller): packed weights of this step, filled on first use and reused
+        while the caller keeps it -- autoregressive generation runs the same step once per frame on unchanged weights."""
         N, C, H, W = x.shape
         Ch = C // 2
         Hd = int(w1.shape[0])
@@ -1010,17 +1012,33 @@ class GlowStepRevFn(torch.autograd.Function):
         cin2 = cond if cond.shape[1] > 0 else None
         fp = fwd_prec(H, W)
         Cc_ = 0 if cin2 is None else int(cin2.shape[1])
+        pkc = pkcache if pkcache is not None else {}
+
+        def cached(key, make):
+            if key not in pkc:
+                pkc[key] = make()
+            return pkc[key]
         if coupling_po_ok(N, C, Cc_, Hd, H, W, w1, w3) and int(w2.shape[2]) == 1:
-            plan = POPackPlan([(w1.detach(), w2.detach(), w3.detach())])
-            plan.run()
-            _, _, P = coupling_po_fwd(z, cin2, plan.bufs[0], f(n1b), f(n1l), f(n2b), f(n2l), C, act)
+            def make_po():
+                plan = POPackPlan([(w1.detach(), w2.detach(), w3.detach())])
+                plan.run()
+                return plan.bufs[0]
+            _, _, P = coupling_po_fwd(z, cin2, cached("po", make_po), f(n1b), f(n1l), f(n2b), f(n2l), C, act)
             o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
             b3f, l3f = f(b3), f(l3)
             L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b3f), L.dev(l3f), L.dev(o), _i(N), _i(C), _i(H), _i(W))
         else:
-            h1 = conv2d_raw(z[:, :Ch], cin2, pack_weight(w1, prec=fp), Hd, int(w1.shape[2]), 1, f(n1b), f(n1l), act, prec=fp)
-            h2 = conv2d_raw(h1, None, pack_weight(w2, prec=fp), Hd, int(w2.shape[2]), 1, f(n2b), f(n2l), act, prec=fp)
-            o = zeros_conv_fwd(h2, w3, f(b3), f(l3), prec=fp)
+            h1 = conv2d_raw(z[:, :Ch], cin2, cached(("w1", fp), lambda: pack_weight(w1, prec=fp)), Hd, int(w1.shape[2]), 1,
+                            f(n1b), f(n1l), act, prec=fp)
+            h2 = conv2d_raw(h1, None, cached(("w2", fp), lambda: pack_weight(w2, prec=fp)), Hd, int(w2.shape[2]), 1,
+                            f(n2b), f(n2l), act, prec=fp)
+            if zeros_conv_uses_taps(w3):
+                C3, Cin3 = int(w3.shape[0]), int(w3.shape[1])
+                pk3 = cached(("w3t", fp), lambda: pack_weight(
+                    w3.detach().permute(2, 3, 0, 1).reshape(9 * C3, Cin3, 1, 1).contiguous(), prec=fp))
+            else:
+                pk3 = cached(("w3", fp), lambda: pack_weight(w3, prec=fp))
+            o = zeros_conv_fwd(h2, w3, f(b3), f(l3), pk3, prec=fp)
         dlogdet = torch.zeros(N, device=x.device, dtype=torch.float32)
         affine_coupling_(z, o, f(scale), f(scale_shift), dlogdet, clamp_type, True)
         out = invconv_actnorm_rev(z, f(an_bias), f(an_logs), Winv.detach())

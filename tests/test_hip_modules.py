@@ -656,6 +656,45 @@ def test_checkpoint_resume_round_trip(tmp_path, conv_precision):
         torch.testing.assert_close(p, q, rtol=1e-5, atol=1e-7, msg=lambda m: n + ": " + m)
 
 
+def test_graphed_generation_equals_eager_generation(conv_precision, monkeypatch):
+    """RFN.predict / RFN.sample replay one generation step per frame from a hipGraph (RFN._gen_step_graphed; the draws
+    are inputs of the graph).  With the generator seeded identically the frames equal those of the eager launches
+    (RFN_GEN_GRAPH=0) up to summation order, also after the weights changed (the graph is rebuilt: inverse matrices and
+    weight packs are baked into it)."""
+    if conv_precision != "mixed":
+        pytest.skip("launch-mode logic: run once")
+    import rfn_hip
+    if not rfn_hip.graph_capture_safe():
+        pytest.skip("hipGraph replay needs DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 before the HIP runtime starts")
+    import __graft_entry__ as ge
+    from RFN import RFN
+    args = ge._tiny_args()
+    torch.manual_seed(5)
+    m = RFN(args).cuda().train()
+    g = torch.Generator().manual_seed(6)
+    x = (torch.rand(args.batch_size, 5, *args.x_dim[1:], generator=g) - 0.5).cuda()
+    m.loss(x, 0)                       # data dependent init
+    m.eval()
+
+    def run(graph):
+        monkeypatch.setenv("RFN_GEN_GRAPH", "1" if graph else "0")
+        torch.manual_seed(11)
+        _, pred = m.predict(x, 3, 2)
+        torch.manual_seed(12)
+        smp = m.sample(x, 3)
+        return pred, smp
+
+    for rnd in range(2):
+        pe, se = run(False)
+        pg, sg = run(True)
+        assert getattr(m, "_gen_graph", None) is not None
+        close(pg.cuda(), pe, 1e-4, 1e-5)
+        close(sg.cuda(), se, 1e-4, 1e-5)
+        with torch.no_grad():          # change the weights: the graph must follow
+            for prm in m.flow.parameters():
+                prm.add_(0.01 * torch.randn_like(prm))
+
+
 def test_training_trajectory_split_precision_vs_fp32_mfma(tmp_path, conv_precision):
     """20 Adam steps on the tiny configuration: the loss trajectory of the shipped arithmetic ('mixed', and 'bf16x3') stays
     on the trajectory of the all-fp32-MFMA kernels -- same initial weights, same batches, same noise (the RNG is re-seeded

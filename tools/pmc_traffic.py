@@ -21,4 +21,25 @@ out = {"kernel": sys.argv[3], "dispatches": [n1, n2], "fetch_bytes_per_launch": 
        "corrections": "KB -> bytes; FETCH_SIZE x2 on gfx950 (128-B requests tallied at 64 B)",
        "command": "rocprofv3 --pmc <counter> -- python3 bench.py --child --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --secondary --no-parity"}
 json.dump(out, open(sys.argv[4], "w"), indent=1)
+# per-kernel aggregate of both passes next to the summary (the raw counter_collection.csv files are hundreds of MB)
+def by_kernel(d, counter):
+    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    agg = {}
+    for r in csv.DictReader(open(f)):
+        if r["Counter_Name"] == counter:
+            a = agg.setdefault(r["Kernel_Name"], [0, 0.0])
+            a[0] += 1
+            a[1] += float(r["Counter_Value"])
+    return agg
+fa, wa = by_kernel(sys.argv[1], "FETCH_SIZE"), by_kernel(sys.argv[2], "WRITE_SIZE")
+with open(sys.argv[4].replace(".json", "_by_kernel.csv"), "w") as f:
+    f.write("kernel,dispatches,mean_FETCH_SIZE_KB_raw,mean_WRITE_SIZE_KB_raw,mean_HBM_bytes_corrected\n")
+    rows = []
+    for k in set(fa) | set(wa):
+        n = max(fa.get(k, [0, 0])[0], wa.get(k, [0, 0])[0])
+        mf = fa[k][1] / fa[k][0] if k in fa else 0.0
+        mw = wa[k][1] / wa[k][0] if k in wa else 0.0
+        rows.append((n * (2 * mf + mw), k, n, mf, mw))
+    for tot, k, n, mf, mw in sorted(rows, reverse=True)[:80]:
+        f.write('"%s",%d,%.1f,%.1f,%.0f\n' % (k[:120].replace('"', "'"), n, mf, mw, (2 * mf + mw) * 1024))
 print(json.dumps(out))
