@@ -33,21 +33,6 @@ struct ConvParams {
     float* part;        // [2][Cout] sums Σ gu, Σ g*y, accumulated with float atomics (caller zeroes)
 };
 
-// Sum over each 32-lane half of a wave with DPP adds (VALU rate; __shfl_xor would go through the LDS crossbar, and the
-// fused activation-backward epilogue needs 128 of these per wave).  The total of lanes 0-31 lands in lanes 16-31, the
-// total of lanes 32-63 in lanes 48-63.
-__device__ __forceinline__ float half_wave_sum_dpp(float v) {
-#define RFN_DPP_ADD(ctrl, rmask)                                                                              \
-    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, rmask, 0xF, true))
-    RFN_DPP_ADD(0xB1, 0xF);   // quad_perm [1,0,3,2]
-    RFN_DPP_ADD(0x4E, 0xF);   // quad_perm [2,3,0,1]
-    RFN_DPP_ADD(0x141, 0xF);  // row_half_mirror
-    RFN_DPP_ADD(0x140, 0xF);  // row_mirror      -> every lane of a 16-lane row holds the row total
-    RFN_DPP_ADD(0x142, 0xA);  // row_bcast15 into rows 1 and 3: += total of the previous row
-#undef RFN_DPP_ADD
-    return v;
-}
-
 // Epilogue shared by the fp32 and the bf16x3 kernels (the C/D register layout of the 32x32 MFMA tile does not depend
 // on the input dtype): per-channel affine + activation, bounds, output split over two tensors, accumulate / atomic.
 // FASTONLY: the caller guarantees full cout tiles, one output tensor, no accumulate / split-K and ep_mode <= 3 -- only the

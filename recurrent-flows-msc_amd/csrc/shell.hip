@@ -333,8 +333,8 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
                 for (int i = 0; i < C; ++i) a = fmaf(Wm[(long)i * C + j], G[i * PBS + px], a);
                 const float gxv = a * expf(logs[j]);
                 if (valid) gx[n * gx_ns + (long)j * HW + p] = gxv;
-                const float s1 = wave_sum(gxv);
-                const float s2 = wave_sum(a * Y[j * PBS + px] + ldc);
+                const float s1 = wave_sum_dpp(gxv);
+                const float s2 = wave_sum_dpp(a * Y[j * PBS + px] + ldc);
                 if ((t & 63) == 0) {
                     atomicAdd(&Bacc[j], s1);
                     atomicAdd(&Lacc[j], s2);
@@ -375,14 +375,14 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
                     tl.gpre[n * tl.gpre_ns + (long)(2 * j) * HW + p] = u0;
                     tl.gpre[n * tl.gpre_ns + (long)(2 * j + 1) * HW + p] = u1;
                 }
-                const float s1a = wave_sum(g1), s1b = wave_sum(g2);
-                const float s2a = wave_sum(a1 * Y[j * PBS + px] + ldc), s2b = wave_sum(a2 * Y[(j + Ch) * PBS + px] + ldc);
-                const float tb0 = wave_sum(u0), tb1 = wave_sum(u1);
-                const float tl0 = wave_sum(gzv * o0), tl1 = wave_sum(go1 * sv);
+                const float s1a = wave_sum_dpp(g1), s1b = wave_sum_dpp(g2);
+                const float s2a = wave_sum_dpp(a1 * Y[j * PBS + px] + ldc), s2b = wave_sum_dpp(a2 * Y[(j + Ch) * PBS + px] + ldc);
+                const float tb0 = wave_sum_dpp(u0), tb1 = wave_sum_dpp(u1);
+                const float tl0 = wave_sum_dpp(gzv * o0), tl1 = wave_sum_dpp(go1 * sv);
                 float tsc = 0.f, tsh = 0.f;
                 if (tl.clamp_type == 0) {
-                    tsc = wave_sum(gls * tanhf(sv));
-                    tsh = wave_sum(gls);
+                    tsc = wave_sum_dpp(gls * tanhf(sv));
+                    tsh = wave_sum_dpp(gls);
                 }
                 if ((t & 63) == 0) {
                     atomicAdd(&Bacc[j], s1a);
@@ -467,13 +467,18 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
     for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
         const long n = q / HW;
         const int p = (int)(q - n * HW);
-        float xr[C], y[C], g[C], gxr[C];
+        float xr[C], y[C], g[C], gxr[C], ov[C];
+        float gld = 0.f;
+        // every load of the iteration is issued up front (one memory round trip per pixel instead of two)
 #pragma unroll
         for (int c = 0; c < C; ++c) {
             xr[c] = x[n * x_ns + (long)c * HW + p];
-            y[c] = (xr[c] + b[c]) * es[c];
             g[c] = gz[n * gz_ns + (long)c * HW + p];
+            ov[c] = TAIL ? tl.o[n * tl.o_ns + (long)c * HW + p] : 0.f;
         }
+        if (TAIL && tl.glogdet) gld = tl.glogdet[n];
+#pragma unroll
+        for (int c = 0; c < C; ++c) y[c] = (xr[c] + b[c]) * es[c];
 #pragma unroll
         for (int j = 0; j < C; ++j) {
             float gy = 0.f;
@@ -489,16 +494,15 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
             al[j] = fmaf(gy, y[j], al[j]);
         }
         if (tl.ld_const && p == 0) {
-            const float ldc = (float)HW * tl.glogdet[n];
+            const float ldc = (float)HW * (TAIL ? gld : tl.glogdet[n]);
 #pragma unroll
             for (int c = 0; c < C; ++c) al[c] += ldc;
         }
         if (TAIL) {
-            const float gld = tl.glogdet ? tl.glogdet[n] : 0.f;
 #pragma unroll
             for (int j = 0; j < Ch; ++j) {
-                const float o0 = tl.o[n * tl.o_ns + (long)(2 * j) * HW + p];
-                const float sv = tl.o[n * tl.o_ns + (long)(2 * j + 1) * HW + p];
+                const float o0 = ov[2 * j];
+                const float sv = ov[2 * j + 1];
                 const float ls = clamp_ls(sv, tl.clamp_type, sc[j], sh[j]);
                 const float gls = gxr[j + Ch] * xr[j + Ch] + gld;
                 const float gzv = gxr[j + Ch] * expf(ls);
@@ -524,16 +528,16 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
     for (int i = 0; i < C; ++i) {
 #pragma unroll
         for (int j = 0; j < C; ++j) {
-            const float v = wave_sum(aW[i][j]);
+            const float v = wave_sum_dpp(aW[i][j]);
             if (lead) atomicAdd(&red[i * C + j], v);
         }
-        const float vb = wave_sum(ab[i]), vl = wave_sum(al[i]);
+        const float vb = wave_sum_dpp(ab[i]), vl = wave_sum_dpp(al[i]);
         if (lead) {
             atomicAdd(&red[C * C + i], vb);
             atomicAdd(&red[C * C + C + i], vl);
         }
         if (TAIL) {
-            const float v0 = wave_sum(tb[i]), v1 = wave_sum(tlg[i]);
+            const float v0 = wave_sum_dpp(tb[i]), v1 = wave_sum_dpp(tlg[i]);
             if (lead) {
                 atomicAdd(&red[C * C + 2 * C + i], v0);
                 atomicAdd(&red[C * C + 3 * C + i], 3.f * v1);
@@ -543,7 +547,7 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_small_kernel(
     if (TAIL && tl.clamp_type == 0) {
 #pragma unroll
         for (int j = 0; j < Ch; ++j) {
-            const float v0 = wave_sum(tsc[j]), v1 = wave_sum(tsh[j]);
+            const float v0 = wave_sum_dpp(tsc[j]), v1 = wave_sum_dpp(tsh[j]);
             if (lead) {
                 atomicAdd(&red[C * C + 4 * C + j], v0);
                 atomicAdd(&red[C * C + 4 * C + Ch + j], v1);
@@ -573,7 +577,9 @@ static int launch_actnorm_invconv_bwd(const float* x, long x_ns, const float* bi
     if (C == 4 || C == 8) {
         long tot = (long)N * HW;
         // few, fat blocks: every block ends with C*C+2C same-address atomics, which serialise at the memory side
-        int grid = (int)((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256);
+        static const int cap_env = getenv("RFN_SHELL_BWD_BLOCKS") ? atoi(getenv("RFN_SHELL_BWD_BLOCKS")) : 0;
+        const int cap = cap_env > 0 ? cap_env : 256;
+        int grid = (int)((tot + 255) / 256 < cap ? (tot + 255) / 256 : cap);
         if (C == 4)
             hipLaunchKernelGGL((actnorm_invconv_bwd_small_kernel<4, TAIL>), dim3(grid), dim3(256), 0, st, x, x_ns, bias,
                                logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW, tl);
@@ -601,7 +607,9 @@ static int launch_actnorm_invconv_bwd(const float* x, long x_ns, const float* bi
     const int jpt = C * PB / 256;  // channels per thread without a split
     if (ny < jpt / 2) ny = jpt / 2;
     if (ny > 8) ny = 8;
-    while (ny > 1 && grid * ny > 2048) ny >>= 1;
+    static const int ycap_env = getenv("RFN_SHELL_BWD_YCAP") ? atoi(getenv("RFN_SHELL_BWD_YCAP")) : 0;
+    const int ycap = ycap_env > 0 ? ycap_env : 512;  // one wave of workgroups: the y-blocks re-stage the same tile
+    while (ny > 1 && grid * ny > ycap) ny >>= 1;
     hipLaunchKernelGGL(actnorm_invconv_bwd_kernel<TAIL>, dim3(grid, ny), dim3(256), lds, st, x, x_ns, bias, logs, Wm, gz,
                        gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB, ntiles, tl);
     return 0;
