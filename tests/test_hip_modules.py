@@ -1021,3 +1021,92 @@ def test_glow_level_node_equals_chain_of_step_nodes(conv_precision, N, C, Cc, S,
     for a, b in zip(g_lv, g_ref):
         assert a.shape == b.shape
         close(a, b.cpu(), 1e-4, 1e-6)
+
+
+def test_baseline_config_unconditional_glow_32x32(conv_precision):
+    """BASELINE.json configs[1]: unconditional Glow on 32x32x3 images, K=8, L=3 (ListGlow with zero-channel conditions,
+    make_conditional=False, learn_prior=False), Hd=256, at its real size: data dependent init + steady-state
+    log-likelihood against the CPU oracle on the same weights and dequantisation noise (<= 1e-4 relative per sample),
+    gradients flow, and sample() from the same z with pinned Split2d draws matches the oracle's."""
+    from Flow import ListGlow
+    from tests.golden_args import GLOW_DEFAULTS
+    a = dict(GLOW_DEFAULTS, L=3, K=8, n_units_affine=256, make_conditional=False, learn_prior=False,
+             non_lin_glow="leakyrelu")
+    B, C, S = 4, 3, 32
+    torch.manual_seed(51)
+    conds_sz = [[B, 0, S >> (l + 1), S >> (l + 1)] for l in range(3)]
+    flow = ListGlow([B, C, S, S], conds_sz, (B, 0, S >> 3, S >> 3), glow_ns(a)).cuda().train()
+    g = torch.Generator().manual_seed(52)
+    x = (torch.rand(B, C, S, S, generator=g) * 255).floor() / 256 - 0.5
+    noise = torch.rand(B, C, S, S, generator=g) / 256
+    conds = [torch.zeros(*sz) for sz in conds_sz]
+    base = torch.zeros(B, 0, S >> 3, S >> 3)
+    cc = [cu(c) for c in conds]
+    flow.log_prob(cu(x), cc, cu(base), 0, noise=cu(noise))         # first call: ActNorm init
+    with torch.no_grad():
+        for prm in flow.parameters():
+            prm.add_(0.01 * torch.randn(prm.shape, generator=g).cuda())
+    z, nll = flow.log_prob(cu(x), cc, cu(base), 0, noise=cu(noise))
+    sd = {k: v.detach().cpu().clone() for k, v in flow.state_dict().items()}
+    with torch.no_grad():
+        zo, nllo = O.listglow_log_prob(sd, "", a, x, conds, base, 0, noise, True)
+    close(z, zo, 1e-4, 1e-4)
+    nll_rel(nll, nllo)
+    nll.mean().backward()
+    assert all(p.grad is not None and bool(torch.isfinite(p.grad).all()) for p in flow.parameters())
+    flow.eval()
+    with torch.no_grad():   # generation at this size (the Split2d levels draw fresh z2: not an inversion of log_prob)
+        eps = [torch.randn(B, 6 * 2 ** l, S >> (l + 1), S >> (l + 1), generator=g) for l in (1, 0)]  # coarsest first
+        xs = flow.sample(z.detach(), cc, cu(base), eps_list=[cu(e) for e in eps])
+        xo = O.listglow_sample(sd, "", a, z.detach().cpu(), conds, base, eps_list=eps)
+    close(xs, xo, 2e-4, 2e-5)
+
+
+def test_baseline_config_bair_shaped_rfn(conv_precision):
+    """BASELINE.json configs[4]: RFN on BAIR-shaped video -- C=3, 64x64, L=4, K=16, Hd=256, skip conditions in the flow
+    (`with_skip`), overshooting D=2 -- one training loss at its real widths (B=2, T=3) against the CPU oracle with pinned
+    draws: KL, NLL and bits/dim within 1e-4 relative; backward runs (grouped weight gradients with K = 16 groups)."""
+    import main_rfn
+    from RFN import RFN
+    argv = ("--extractor_structure 32-32-pool-64 64-pool-128 128-pool-256 256-pool-512 "
+            "--upscaler_structure 256 upsample-128-128 upsample-64-64 upsample-32-32 "
+            "--prior_structure 256 256 --encoder_structure 256 256 --make_conditional --learn_prior "
+            "--skip_connection_features --flow_norm actnorm --structure_scaler 2 --choose_data bair "
+            "--n_units_affine 256 --n_units_prior 256 --temperature 0.7 --norm_type none --z_dim 32 --h_dim 128 "
+            "--n_bits 8 --n_frames 3 --image_size 64 --K 16 --L 4 --D 2 --overshot_w 0.5 "
+            "--x_dim 2 3 64 64 --condition_dim 2 3 64 64 --batch_size 2 "
+            "--skip_connection_flow with_skip --no-upscaler_tanh --no-downscaler_tanh --synthetic_data").split()
+    args = main_rfn.build_parser().parse_args(argv)
+    B, T = 2, 3
+    torch.manual_seed(61)
+    m = RFN(args).cuda().train()
+    g = torch.Generator().manual_seed(62)
+    x = (torch.rand(B, T, 3, 64, 64, generator=g) * 255).floor() / 256 - 0.5
+    hu = 64 >> 4
+    zshape = (B, args.z_dim, hu, hu)
+
+    def draws():
+        gg = torch.Generator().manual_seed(63)
+        d = []
+        for _ in range(T - 1):
+            d += [torch.randn(zshape, generator=gg), torch.randn(zshape, generator=gg),
+                  torch.rand(B, 3, 64, 64, generator=gg) / 256]
+        for _ in range(8):                      # overshooting prior draws (more than needed is fine)
+            d.append(torch.randn(zshape, generator=gg))
+        return d
+    with torch.no_grad():
+        m.loss(cu(x), 0, draws=draws())       # data dependent init
+        for prm in m.flow.parameters():
+            prm.add_(0.003 * torch.randn(prm.shape, generator=g).cuda())
+    kl_fb, kl, nll = m.loss(cu(x), 0, draws=draws())
+    sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        r = O.rfn_loss(sd, vars(args), x, draws(), True)
+    for a_, b_ in zip((kl_fb, kl, nll), r):
+        assert abs(float(a_) - float(b_)) <= 1e-4 * abs(float(b_)) + 1e-5, (float(a_), float(b_))
+    bpd = O.bits_per_dim(kl.detach().cpu(), nll.detach().cpu(), x.shape[2:], T - 1)
+    bpd_o = O.bits_per_dim(r[1], r[2], x.shape[2:], T - 1)
+    assert abs(bpd - bpd_o) <= 1e-4 * abs(bpd_o)
+    (nll + 0.5 * kl_fb).backward()
+    assert all(bool(torch.isfinite(p.grad).all()) for p in m.parameters() if p.grad is not None)
+    assert sum(p.grad is not None for p in m.flow.parameters()) > 0
