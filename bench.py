@@ -41,12 +41,13 @@ def make_batch(B, T, seed, device):
     return torch.stack([ds[i] for i in range(B)]).to(device)
 
 
-def build_solver(B_local, T, device, lr=1e-4):
+def build_solver(B_local, T, device, lr=1e-4, argv=None):
+    """`argv` (optional): another configuration than the canonical SM-MNIST one (tools/bench_config.py)"""
     import main_rfn
     from RFN.trainer import Solver
     from RFN import RFN
     from rfn_hip import dist as rdist
-    args = main_rfn.build_parser().parse_args(main_rfn.canonical_smmnist_argv(B_local, T))
+    args = main_rfn.build_parser().parse_args(argv if argv is not None else main_rfn.canonical_smmnist_argv(B_local, T))
     args.path = "/gpurun_out/bench_tmp/"
     s = Solver(args)
     s.device = device
