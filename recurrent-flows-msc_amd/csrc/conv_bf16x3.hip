@@ -363,8 +363,19 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
         for (int r = 0; r < 16; ++r) acc[0][0][r] += accx[0][r] + accx[1][r];
     }
 
+    float* psum = ep + 2 * BCO;  // [BCO][2] sums of the fused activation backward (ep_mode 4)
+    if (p.ep_mode == 4)
+        for (int c = tid; c < 2 * BCO; c += 256) psum[c] = 0.f;
     __syncthreads();
-    conv_epilogue<TCO, TPX, BCO>(p, acc, ep, co_base, wco, kk, HW, pn, ppix, pvalid, blockIdx.x * WPX + wpx);
+    conv_epilogue<TCO, TPX, BCO>(p, acc, ep, co_base, wco, kk, HW, pn, ppix, pvalid, blockIdx.x * WPX + wpx,
+                                 p.ep_mode == 4 ? psum : nullptr, true);
+    if (p.ep_mode == 4) {
+        __syncthreads();
+        for (int c = tid; c < 2 * BCO; c += 256) {
+            const int co = blockIdx.y * BCO + (c >> 1);
+            if (co < p.Cout) atomicAdd(&p.part[(long)(c & 1) * p.Cout + co], psum[c]);
+        }
+    }
 }
 
 template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
@@ -383,7 +394,7 @@ static int launch_conv_b3(ConvParams& p, hipStream_t s) {
         rfn_set_error("conv2d(bf16x3): map %dx%d needs %d LDS slots (> %d supported)", p.H, p.W, IMG, P2 * NPOS);
         return -7;
     }
-    size_t lds = (size_t)2 * (KC / 8) * IMG * 16 + (size_t)(KC / 16) * KS * KS * 4 * BCO * 16 + 2 * BCO * 4;
+    size_t lds = (size_t)2 * (KC / 8) * IMG * 16 + (size_t)(KC / 16) * KS * KS * 4 * BCO * 16 + 4 * BCO * 4;
     auto kern = conv_b3_kernel<KS, WCO, WPX, TCO, TPX, KC>;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(p.n_wtiles * p.n_htiles * p.n_ftiles, ceil_div(p.Cout, BCO));

@@ -42,7 +42,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                                               const int co_base, const int wco, const int kk, const int HW,
                                               const int (&pn)[TPX], const int (&ppix)[TPX],
                                               const bool (&pvalid)[TPX], const int prow = 0,
-                                              float* const lds_part = nullptr) {
+                                              float* const lds_part = nullptr, const bool lds_shared = false) {
     const int cl_base = wco * (32 * TCO) + 4 * kk;  // channel index inside the block for (a=0, r=0)
     const bool fast = FASTONLY || ((co_base + 32 * TCO <= p.Cout) && (p.cout_split == p.Cout));  // wave-uniform
     if (!FASTONLY && p.ep_mode == 4) {
@@ -89,7 +89,15 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 sb = half_wave_sum_dpp(sb);  // lanes of one 32-lane half share the channel
                 sl = half_wave_sum_dpp(sl);
                 if (l31 == 16) {
-                    if (lds_part) {
+                    if (lds_part && lds_shared) {
+                        // generic kernel: the workgroup's waves along the pixel axis share a channel -> LDS atomics; the
+                        // workgroup then flushes [BCO][2] with full-width atomic instructions (a global float atomic is
+                        // charged per WAVE INSTRUCTION, ~50 ns per CU, however few lanes are active: issuing them from
+                        // here, two lanes at a time, cost 60-100 us per launch at the 8x8 / 4x4 levels)
+                        float* dst = lds_part + (cl_base + cidx) * 2;
+                        atomicAdd(dst, sb);
+                        atomicAdd(dst + 1, sl);
+                    } else if (lds_part) {
                         // persistent kernels: running sums of the workgroup in LDS [BCO][2] (this lane is the only
                         // owner of its channel), flushed once per workgroup instead of one row per pixel tile
                         float* dst = lds_part + (cl_base + cidx) * 2;
