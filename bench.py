@@ -71,6 +71,8 @@ def kernel_roofline(rec, steps):
         """MFMA roof of a kernel symbol: the fp32-MFMA kernels (csrc/conv.hip) against 157.3 TFLOP/s, every split kernel
         (bf16x3, f16x3s: three 16-bit MFMAs per fp32 product) against 2500 / 3"""
         f32k = sym.startswith("conv_mfma_kernel") or sym.startswith("wgrad_mfma_kernel")
+        if sym.endswith(" x6"):  # bf16x6: six MFMAs per fp32 product
+            return PEAK_BF16_MFMA_TFLOPS / 6.0
         return PEAK_F32_MFMA_TFLOPS if f32k else PEAK_BF16_MFMA_TFLOPS / 3.0
     groups, shapes = {}, {}
     for name, meta, e0, e1 in rec:
@@ -253,7 +255,7 @@ def parity_check(device, T=10, scales=(0.003, 0.01, 0.1)):
     return res
 
 
-DTYPE_STR = {"mixed": "f32 (forward convolutions fp32-grade: fused scaled-fp16 split f16x3s / v_mfma_f32_32x32x2_f32; "
+DTYPE_STR = {"mixed": "f32 (forward convolutions fp32-grade: fused scaled-fp16 split f16x3s / three-piece bf16x6 split; "
                       "gradient convolutions bf16x3 split MFMA; fp32 accumulate everywhere)",
              "bf16x3": "f32 (convolutions: bf16x3 split-precision MFMA, fp32 accumulate)",
              "f32": "f32 (convolutions: v_mfma_f32_32x32x2_f32)"}

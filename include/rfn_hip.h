@@ -85,6 +85,16 @@ int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, const float* in
 long rfn_packed_weight_size_bf16x3(int Cout, int Cin, int ks); /* in floats (4-byte units) */
 int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
                                 rfn_stream_t stream);
+/* "bf16x6": three bf16 pieces per operand (24 significant bits), six MFMAs per product -- fp32-grade results at twice
+ * the cost of bf16x3 and a third of the fp32-MFMA kernel's; the forward convolutions of the flow levels the fused kernel
+ * does not take ('mixed' arithmetic).  Same arguments as the bf16x3 functions; generic tile kernel only. */
+long rfn_packed_weight_size_bf16x6(int Cout, int Cin, int ks);
+int rfn_pack_conv_weight_bf16x6(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
+                                rfn_stream_t stream);
+int rfn_conv2d_fwd_bf16x6(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                          const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                          int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
+                          const float* p0, const float* p1, int act, rfn_stream_t stream);
 
 /* Data-gradient convolution fused with the backward of the PRODUCER conv's Conv2dNorm epilogue (ActNorm + ActFun,
  * glow_modules.py:139-142 + Utils/modules.py:8-19): with y = act((u+b)*exp(logs)) saved from the forward pass,
@@ -100,8 +110,9 @@ int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Cin, const fl
 
 /* Pack MANY weights in one launch (a whole flow: ~300 descriptors per training step instead of ~370 launches).
  * descs_device: device array of n rfn_pack_desc; mode 0 forward, 1 data-gradient (transposed, taps mirrored),
- * 2 tap-expanded 1x1 form of a 3x3 conv with tiny Cout (w'[tap*Cout+co][ci] = w[co][ci][tap]).  Each wpk must hold
- * rfn_packed_weight_size_bf16x3 floats of the LOGICAL conv (mode 2: Cout' = 9*Cout, ks' = 1). */
+ * 2 tap-expanded 1x1 form of a 3x3 conv with tiny Cout (w'[tap*Cout+co][ci] = w[co][ci][tap]); mode + 4: three planes
+ * (bf16x6) instead of two.  Each wpk must hold rfn_packed_weight_size_bf16x3 (or _bf16x6) floats of the LOGICAL conv
+ * (mode 2: Cout' = 9*Cout, ks' = 1). */
 typedef struct {
     const float* w;
     float* wpk;

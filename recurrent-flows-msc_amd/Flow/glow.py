@@ -198,13 +198,15 @@ class ListGlow(nn.Module):
                 w1, w2, w3 = n0.conv.weight, n2.conv.weight, n4.conv.weight
                 fused = s.flow_norm != "batchnorm" and int(w2.shape[2]) == 1 and \
                     K.coupling_po_ok(N, C, Cc, int(w1.shape[0]), H, W, w1, w3)
-                b3fwd = not fused and K.fwd_prec(H, W) == "bf16x3"
+                fp = K.fwd_prec(H, W)
+                b3fwd = not fused and fp in ("bf16x3", "bf16x6")
+                x6 = 4 if fp == "bf16x6" else 0   # forward packs in three planes where bf16x6 is the forward arithmetic
                 slot = [None] * 7
                 for j, (w, mode) in enumerate(((w1, 0), (w1, 1), (w2, 0), (w2, 1),
                                                (w3, 2 if K.zeros_conv_uses_taps(w3) else 0), (w3, 1))):
                     if j % 2 == 1 or b3fwd:
                         slot[j] = len(items)
-                        items.append((w, mode))
+                        items.append((w, mode + (x6 if j % 2 == 0 else 0)))
                 if fused:
                     slot[6] = len(nets)
                     nets.append((w1, w2, w3))

@@ -23,8 +23,9 @@ static inline void packed_dims_b3(int Cout_l, int Cin_l, int* CoutP, int* Cin16)
 }
 
 // packed unit (16 bytes = 8 bf16) index: (((c16*T + tap)*2 + plane)*2 + g)*CoutP + co ; element j <-> cin = c16*16+g*8+j
+// NPL = 2: (hi, lo) -- bf16x3;  NPL = 3: (hi, mid, lo), 24 significant bits -- "bf16x6" (six products per fp32 product)
 __global__ void pack_weight_b3_kernel(const float* __restrict__ w, bf16x8* __restrict__ wpk, int Cout, int Cin, int KS,
-                                      int CoutP, int Cin16, int transpose_flip) {
+                                      int CoutP, int Cin16, int transpose_flip, int NPL) {
     const int T = KS * KS;
     const int Co_l = transpose_flip ? Cin : Cout;
     const int Ci_l = transpose_flip ? Cout : Cin;
@@ -36,7 +37,7 @@ __global__ void pack_weight_b3_kernel(const float* __restrict__ w, bf16x8* __res
         r >>= 1;
         const int tap = (int)(r % T);
         const int c16 = (int)(r / T);
-        bf16x8 hi, lo;
+        bf16x8 hi, lo, l3;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ci = c16 * 16 + g * 8 + j;
@@ -44,12 +45,16 @@ __global__ void pack_weight_b3_kernel(const float* __restrict__ w, bf16x8* __res
             if (co < Co_l && ci < Ci_l)
                 v = transpose_flip ? w[((long)ci * Cin + co) * T + (T - 1 - tap)] : w[((long)co * Cin + ci) * T + tap];
             const __bf16 h = (__bf16)v;
+            const float r1 = v - (float)h;
+            const __bf16 m = (__bf16)r1;
             hi[j] = h;
-            lo[j] = (__bf16)(v - (float)h);
+            lo[j] = m;
+            l3[j] = (__bf16)(r1 - (float)m);
         }
-        const long base = ((long)(c16 * T + tap) * 2) * 2 * CoutP;
+        const long base = ((long)(c16 * T + tap) * NPL) * 2 * CoutP;
         wpk[base + (long)(0 * 2 + g) * CoutP + co] = hi;
         wpk[base + (long)(1 * 2 + g) * CoutP + co] = lo;
+        if (NPL == 3) wpk[base + (long)(2 * 2 + g) * CoutP + co] = l3;
     }
 }
 
@@ -61,9 +66,22 @@ extern "C" long rfn_packed_weight_size_bf16x3(int Cout, int Cin, int ks) {
     long s0 = (long)b * ks * ks * 4 * a * 4, s1 = (long)d * ks * ks * 4 * c * 4;  // units * 16 B / 4 B
     return s0 > s1 ? s0 : s1;
 }
+extern "C" long rfn_packed_weight_size_bf16x6(int Cout, int Cin, int ks) {
+    return rfn_packed_weight_size_bf16x3(Cout, Cin, ks) / 2 * 3;  // three planes instead of two
+}
 
+static int pack_conv_weight_planes(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip, int NPL,
+                                   rfn_stream_t stream);
 extern "C" int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
                                            rfn_stream_t stream) {
+    return pack_conv_weight_planes(w, wpk, Cout, Cin, ks, transpose_flip, 2, stream);
+}
+extern "C" int rfn_pack_conv_weight_bf16x6(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip,
+                                           rfn_stream_t stream) {
+    return pack_conv_weight_planes(w, wpk, Cout, Cin, ks, transpose_flip, 3, stream);
+}
+static int pack_conv_weight_planes(const float* w, float* wpk, int Cout, int Cin, int ks, int transpose_flip, int NPL,
+                                   rfn_stream_t stream) {
     RFN_CHECK_ARG(w && wpk && Cout > 0 && Cin > 0 && (ks == 1 || ks == 3), -1);
     RFN_CHECK_ARG(((uintptr_t)wpk & 15) == 0, -2);
     int CoutP, Cin16;
@@ -74,7 +92,7 @@ extern "C" int rfn_pack_conv_weight_bf16x3(const float* w, float* wpk, int Cout,
     long total = (long)Cin16 * ks * ks * 2 * CoutP;
     int grid = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
     hipLaunchKernelGGL(pack_weight_b3_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w,
-                       reinterpret_cast<bf16x8*>(wpk), Cout, Cin, ks, CoutP, Cin16, transpose_flip);
+                       reinterpret_cast<bf16x8*>(wpk), Cout, Cin, ks, CoutP, Cin16, transpose_flip, NPL);
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -90,9 +108,10 @@ struct PackDesc {  // mirrors rfn_pack_desc in include/rfn_hip.h
 __global__ void pack_weights_batched_b3_kernel(const PackDesc* __restrict__ descs) {
     const PackDesc d = descs[blockIdx.y];
     const int T_src = d.ks * d.ks;
+    const int NPL = (d.mode & 4) ? 3 : 2, mode = d.mode & 3;  // (mode + 4: three planes = bf16x6)
     int Co_l, Ci_l, T;
-    if (d.mode == 0) { Co_l = d.Cout; Ci_l = d.Cin; T = T_src; }
-    else if (d.mode == 1) { Co_l = d.Cin; Ci_l = d.Cout; T = T_src; }
+    if (mode == 0) { Co_l = d.Cout; Ci_l = d.Cin; T = T_src; }
+    else if (mode == 1) { Co_l = d.Cin; Ci_l = d.Cout; T = T_src; }
     else { Co_l = T_src * d.Cout; Ci_l = d.Cin; T = 1; }
     const int CoutP = ((Co_l + 255) / 256) * 256, Cin16 = (Ci_l + 15) / 16;
     bf16x8* wpk = reinterpret_cast<bf16x8*>(d.wpk);
@@ -104,26 +123,30 @@ __global__ void pack_weights_batched_b3_kernel(const PackDesc* __restrict__ desc
         r >>= 1;
         const int tap = (int)(r % T);
         const int c16 = (int)(r / T);
-        bf16x8 hi, lo;
+        bf16x8 hi, lo, l3;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int ci = c16 * 16 + g * 8 + j;
             float v = 0.f;
             if (co < Co_l && ci < Ci_l) {
-                if (d.mode == 0)
+                if (mode == 0)
                     v = d.w[((long)co * d.Cin + ci) * T_src + tap];
-                else if (d.mode == 1)
+                else if (mode == 1)
                     v = d.w[((long)ci * d.Cin + co) * T_src + (T_src - 1 - tap)];
                 else
                     v = d.w[((long)(co % d.Cout) * d.Cin + ci) * T_src + co / d.Cout];
             }
             const __bf16 h = (__bf16)v;
+            const float r1 = v - (float)h;
+            const __bf16 m = (__bf16)r1;
             hi[j] = h;
-            lo[j] = (__bf16)(v - (float)h);
+            lo[j] = m;
+            l3[j] = (__bf16)(r1 - (float)m);
         }
-        const long base = ((long)(c16 * T + tap) * 2) * 2 * CoutP;
+        const long base = ((long)(c16 * T + tap) * NPL) * 2 * CoutP;
         wpk[base + (long)(0 * 2 + g) * CoutP + co] = hi;
         wpk[base + (long)(1 * 2 + g) * CoutP + co] = lo;
+        if (NPL == 3) wpk[base + (long)(2 * 2 + g) * CoutP + co] = l3;
     }
 }
 extern "C" int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_stream_t stream) {
@@ -135,7 +158,9 @@ extern "C" int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, in
     return 0;
 }
 
-template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
+// NPL = 2: two bf16 pieces per operand, three products (bf16x3); NPL = 3: three pieces, six products ("bf16x6", 24
+// significant bits: the fp32-grade arithmetic of the forward convolutions at the levels the fused kernel does not take)
+template <int KS, int WCO, int WPX, int TCO, int TPX, int KC, int NPL = 2>
 __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
     constexpr int T = KS * KS, PAD = KS / 2;
     constexpr int BCO = 32 * TCO * WCO, BPX = 32 * TPX * WPX;
@@ -161,8 +186,8 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
 
     // LDS: Bs[plane][NG][IMG] units | Ws[NS*T][plane][2][BCO] units | ep[2][BCO] floats
     bf16x8* Bs = reinterpret_cast<bf16x8*>(lds_raw);
-    bf16x8* Ws = Bs + 2 * NG * IMG;
-    float* ep = reinterpret_cast<float*>(Ws + NS * T * 4 * BCO);
+    bf16x8* Ws = Bs + NPL * NG * IMG;
+    float* ep = reinterpret_cast<float*>(Ws + NS * T * NPL * 2 * BCO);
 
     int lds_off[TPX], pn[TPX], ppix[TPX];
     bool pvalid[TPX];
@@ -244,17 +269,21 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
 #pragma unroll
                 for (int j = 0; j < NPOS; ++j) {
                     if (sin[j]) {
-                        bf16x8 hi, lo;
+                        bf16x8 hi, lo, l3;
 #pragma unroll
                         for (int c = 0; c < 8; ++c) {
                             const float v = stg[i][j][c];
                             const __bf16 h = (__bf16)v;
+                            const float r1 = v - (float)h;
+                            const __bf16 m = (__bf16)r1;
                             hi[c] = h;
-                            lo[c] = (__bf16)(v - (float)h);
+                            lo[c] = m;
+                            if (NPL == 3) l3[c] = (__bf16)(r1 - (float)m);
                         }
                         const int r = slot + P2 * j;
                         Bs[(0 * NG + gi) * IMG + r] = hi;
                         Bs[(1 * NG + gi) * IMG + r] = lo;
+                        if (NPL == 3) Bs[(2 * NG + gi) * IMG + r] = l3;
                     }
                 }
             }
@@ -264,7 +293,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
     // ---- weight tile of a chunk: verbatim copy of NS*T*4 runs of BCO units from the packed buffer
     const int total_it = p.Cin8 * T;  // Cin8 holds Cin16 for this kernel
     const u32x4* wp4 = reinterpret_cast<const u32x4*>(p.wpk);
-    constexpr int WRUNS = NS * T * 4;
+    constexpr int WRUNS = NS * T * NPL * 2;
     constexpr int WPT = (WRUNS * BCO + 255) / 256;
     u32x4* Ws4 = reinterpret_cast<u32x4*>(Ws);
     const long wblk = (long)blockIdx.y * BCO;
@@ -275,9 +304,9 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
         for (int j = 0; j < WPT; ++j) {
             const int e = tid + 256 * j;
             const int run = e / BCO, col = e % BCO;
-            const int itg = it0 + (run >> 2);
+            const int itg = it0 + run / (NPL * 2);
             const bool ok = (WRUNS * BCO % 256 == 0 || e < WRUNS * BCO) && itg < total_it;
-            const u32x4 v = wp4[((long)(ok ? itg : 0) * 4 + (run & 3)) * p.CoutP + wblk + col];
+            const u32x4 v = wp4[((long)(ok ? itg : 0) * (NPL * 2) + run % (NPL * 2)) * p.CoutP + wblk + col];
             wstg[j] = ok ? v : u32x4{0u, 0u, 0u, 0u};
         }
     };
@@ -327,23 +356,42 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
             for (int tap = 0; tap < T; ++tap) {
                 const int itl = s * T + tap;
                 const int tapoff = (tap / KS) * RW + (tap % KS);
-                bf16x8 ah[TCO], al[TCO], bh[TPX], bl[TPX];
+                bf16x8 ah[TCO], al[TCO], a3[TCO], bh[TPX], bl[TPX], b3[TPX];
 #pragma unroll
                 for (int a = 0; a < TCO; ++a) {
-                    ah[a] = wa[((itl * 2 + 0) * 2) * BCO + a * 32];
-                    al[a] = wa[((itl * 2 + 1) * 2) * BCO + a * 32];
+                    ah[a] = wa[((itl * NPL + 0) * 2) * BCO + a * 32];
+                    al[a] = wa[((itl * NPL + 1) * 2) * BCO + a * 32];
+                    if (NPL == 3) a3[a] = wa[((itl * NPL + 2) * 2) * BCO + a * 32];
                 }
                 const bf16x8* bb = Bs + (2 * s + kk) * IMG + tapoff;
 #pragma unroll
                 for (int t = 0; t < TPX; ++t) {
                     bh[t] = bb[lds_off[t]];
                     bl[t] = bb[NG * IMG + lds_off[t]];
+                    if (NPL == 3) b3[t] = bb[2 * NG * IMG + lds_off[t]];
                 }
 #pragma unroll
                 for (int a = 0; a < TCO; ++a)
 #pragma unroll
                     for (int t = 0; t < TPX; ++t) {
-                        if (SINGLE) {
+                        if (NPL == 3) {
+                            // six products, smallest first: mid*mid, hi*lo3, lo3*hi, hi*mid, mid*hi, hi*hi
+                            if (SINGLE) {
+                                accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bl[t], accx[0], 0, 0, 0);
+                                accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], b3[t], accx[1], 0, 0, 0);
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[a], bh[t], acc[a][t], 0, 0, 0);
+                                accx[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[t], accx[0], 0, 0, 0);
+                                accx[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[t], accx[1], 0, 0, 0);
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[t], acc[a][t], 0, 0, 0);
+                            } else {
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bl[t], acc[a][t], 0, 0, 0);
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], b3[t], acc[a][t], 0, 0, 0);
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a3[a], bh[t], acc[a][t], 0, 0, 0);
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bl[t], acc[a][t], 0, 0, 0);
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[a], bh[t], acc[a][t], 0, 0, 0);
+                                acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[t], acc[a][t], 0, 0, 0);
+                            }
+                        } else if (SINGLE) {
                             // one accumulator tile per wave: three independent chains instead of one of 3*T*NS
                             // dependent MFMAs per chunk (each waits for the previous result)
                             acc[a][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[a], bh[t], acc[a][t], 0, 0, 0);
@@ -378,7 +426,7 @@ __global__ __launch_bounds__(256) void conv_b3_kernel(const ConvParams p) {
     }
 }
 
-template <int KS, int WCO, int WPX, int TCO, int TPX, int KC>
+template <int KS, int WCO, int WPX, int TCO, int TPX, int KC, int NPL = 2>
 static int launch_conv_b3(ConvParams& p, hipStream_t s) {
     constexpr int BCO = 32 * TCO * WCO, BPX = 32 * TPX * WPX, PAD = KS / 2;
     tile_geometry(p.H, p.W, BPX, &p.TWp, &p.TH, &p.TF);
@@ -394,8 +442,8 @@ static int launch_conv_b3(ConvParams& p, hipStream_t s) {
         rfn_set_error("conv2d(bf16x3): map %dx%d needs %d LDS slots (> %d supported)", p.H, p.W, IMG, P2 * NPOS);
         return -7;
     }
-    size_t lds = (size_t)2 * (KC / 8) * IMG * 16 + (size_t)(KC / 16) * KS * KS * 4 * BCO * 16 + 4 * BCO * 4;
-    auto kern = conv_b3_kernel<KS, WCO, WPX, TCO, TPX, KC>;
+    size_t lds = (size_t)NPL * (KC / 8) * IMG * 16 + (size_t)(KC / 16) * KS * KS * NPL * 2 * BCO * 16 + 4 * BCO * 4;
+    auto kern = conv_b3_kernel<KS, WCO, WPX, TCO, TPX, KC, NPL>;
     if (lds > 65536) (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(p.n_wtiles * p.n_htiles * p.n_ftiles, ceil_div(p.Cout, BCO));
     p.ksplit = 1;
@@ -468,6 +516,7 @@ extern "C" int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Ci
     return 0;
 }
 
+static thread_local int g_conv_npl = 0;  // set by rfn_conv2d_fwd_bf16x6 around its call of the shared entry point
 extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
                                      const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
                                      int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
@@ -487,10 +536,23 @@ extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, cons
     p.N = N; p.H = H; p.W = W;
     packed_dims_b3(Cout, C1 + C2, &p.CoutP, &p.Cin8);
     p.ep_mode = ep_mode; p.act = act; p.p0 = p0; p.p1 = p1;
+    p.npl = g_conv_npl;
     int rc = dispatch_conv_b3(p, ks, (hipStream_t)stream);
     if (rc) return rc;
     RFN_LAUNCH_CHECK();
     return 0;
+}
+// same convolution on three bf16 pieces per operand and six MFMAs per product (24 significant bits, fp32-grade): wpk from
+// rfn_pack_conv_weight_bf16x6
+extern "C" int rfn_conv2d_fwd_bf16x6(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                                     const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                                     int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
+                                     const float* p0, const float* p1, int act, rfn_stream_t stream) {
+    g_conv_npl = 3;
+    const int rc = rfn_conv2d_fwd_bf16x3(in1, in1_ns, C1, in2, in2_ns, C2, wpk, out1, out1_ns, out2, out2_ns, Cout,
+                                         cout_split, acc1, acc2, N, H, W, ks, ep_mode, p0, p1, act, stream);
+    g_conv_npl = 0;
+    return rc;
 }
 
 
@@ -860,6 +922,26 @@ static int dispatch_conv_b3(ConvParams& p, int ks, hipStream_t s) {
     const int Cout = p.Cout, N = p.N, H = p.H, W = p.W;
     const bool few_px = (long)N * H * W * ((Cout + 127) / 128) < 256L * 128;
     int rc;
+    if (p.npl == 3) {  // bf16x6: the generic tile kernel only (forward convolutions of the middle flow levels)
+        if (ks == 3) {
+            if (Cout <= 32)
+                rc = launch_conv_b3<3, 1, 4, 1, 1, 16, 3>(p, s);
+            else if (few_px)
+                rc = launch_conv_b3<3, 2, 2, 1, 1, 16, 3>(p, s);
+            else
+                rc = launch_conv_b3<3, 2, 2, 1, 2, 16, 3>(p, s);
+        } else {
+            if (Cout <= 32)
+                rc = launch_conv_b3<1, 1, 4, 1, 1, 32, 3>(p, s);
+            else if (few_px || Cout <= 64)
+                rc = launch_conv_b3<1, 2, 2, 1, 1, 32, 3>(p, s);
+            else if (Cout <= 128)
+                rc = launch_conv_b3<1, 2, 2, 2, 2, 32, 3>(p, s);
+            else
+                rc = launch_conv_b3<1, 4, 1, 2, 2, 32, 3>(p, s);
+        }
+        return rc;
+    }
     if (conv1x1_ws_eligible(ks, p.C1 + p.C2, p.C2, Cout, (long)N * H * W)) return launch_conv1x1_ws(p, s);
     if (conv3x3_ws_eligible(p, ks)) return launch_conv3x3_ws(p, s);
     if (ks == 3) {

@@ -30,6 +30,7 @@ struct ConvParams {
     // ep_mode 4 (data-gradient conv fused with the backward of the producer's ActNorm+activation epilogue):
     const float* ybuf;  // saved forward activation y = act((u+b)*exp(l)), same shape as the output
     long ybuf_ns;
+    int npl;            // split-precision planes per operand: 0 / 2 = bf16x3, 3 = bf16x6 (generic tile kernel only)
     float* part;        // [2][Cout] sums Σ gu, Σ g*y, accumulated with float atomics (caller zeroes)
 };
 

@@ -33,6 +33,10 @@ SIGNATURES = {
                               _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
     "rfn_packed_weight_size_bf16x3": [_c_i, _c_i, _c_i],
     "rfn_pack_conv_weight_bf16x3": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_packed_weight_size_bf16x6": [_c_i, _c_i, _c_i],
+    "rfn_pack_conv_weight_bf16x6": [_c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_conv2d_fwd_bf16x6": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
+                              _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
     "rfn_conv2d_dgrad_act_rows_bf16x3": [_c_i, _c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_conv2d_dgrad_act_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_i, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,
                                     _c_i, _c_i, _c_s],
@@ -101,7 +105,8 @@ SIGNATURES = {
                                    _c_l, _c_i, _c_i, _c_i, _c_s],
 }
 _RESTYPES = {"rfn_last_error": ctypes.c_char_p, "rfn_packed_weight_size": ctypes.c_long,
-             "rfn_packed_weight_size_bf16x3": ctypes.c_long, "rfn_smallmap_packed_size": ctypes.c_long,
+             "rfn_packed_weight_size_bf16x3": ctypes.c_long, "rfn_packed_weight_size_bf16x6": ctypes.c_long,
+             "rfn_smallmap_packed_size": ctypes.c_long,
              "rfn_coupling_po_packed_bytes": ctypes.c_long}
 
 _lib = None

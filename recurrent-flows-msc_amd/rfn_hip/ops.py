@@ -32,10 +32,14 @@ def bwd_b3():
     return CONV_PRECISION in ("bf16x3", "mixed")
 
 
+MIXED_FWD = os.environ.get("RFN_MIXED_FWD", "bf16x6")  # fp32-grade arithmetic of the unfused forward convs: bf16x6 | f32
+
+
 def fwd_prec(H, W):
-    """arithmetic of an (unfused) forward convolution on an H x W map: 'bf16x3' or 'f32'"""
+    """arithmetic of an (unfused) forward convolution on an H x W map: 'bf16x3', 'bf16x6' (three bf16 pieces per operand,
+    six MFMAs per product: fp32-grade at a third of the fp32-MFMA cost) or 'f32'"""
     if CONV_PRECISION == "mixed":
-        return "bf16x3" if H * W <= 4 else "f32"
+        return "bf16x3" if H * W <= 4 else MIXED_FWD
     return CONV_PRECISION
 
 ACT = {"none": 0, "relu": 1, "leakyrelu": 2}
@@ -138,14 +142,15 @@ def invconv_actnorm_rev(z, bias, logs, Winv):
 def pack_weight(w, flip=False, prec=None):
     """Pack a torch-layout conv weight [Cout,Cin,k,k] for the MFMA conv kernel (flip=True: data-gradient conv).
     One streaming kernel over the packed buffer; done per call (weights change every optimizer step).
-    prec: 'bf16x3' | 'f32' (default: the gradient arithmetic, which is what un-annotated callers are)."""
+    prec: 'bf16x3' | 'bf16x6' | 'f32' (default: the gradient arithmetic, which is what un-annotated callers are)."""
     Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-    b3 = (prec == "bf16x3") if prec is not None else bwd_b3()
-    size = (L.load().rfn_packed_weight_size_bf16x3 if b3 else L.load().rfn_packed_weight_size)(Cout, Cin, ks)
+    prec = prec if prec is not None else ("bf16x3" if bwd_b3() else "f32")
+    sfx = {"bf16x3": "_bf16x3", "bf16x6": "_bf16x6", "f32": ""}[prec]
+    size = getattr(L.load(), "rfn_packed_weight_size" + sfx)(Cout, Cin, ks)
     wpk = torch.empty(size, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    L.call("rfn_pack_conv_weight_bf16x3" if b3 else "rfn_pack_conv_weight_f32", L.dev(wc, "w"), L.dev(wpk), _i(Cout),
-           _i(Cin), _i(ks), _i(1 if flip else 0))
+    L.call("rfn_pack_conv_weight" + (sfx if sfx else "_f32"), L.dev(wc, "w"), L.dev(wpk), _i(Cout), _i(Cin), _i(ks),
+           _i(1 if flip else 0))
     return wpk
 
 
@@ -169,7 +174,8 @@ def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks, arena=None):
 
 class PackPlan:
     """Persistent packed-weight buffers for a list of (weight, mode) and ONE launch that refreshes all of them
-    (rfn_pack_conv_weights_batched_bf16x3).  mode: 0 forward, 1 data-gradient, 2 tap-expanded 1x1 (tiny-Cout 3x3)."""
+    (rfn_pack_conv_weights_batched_bf16x3).  mode: 0 forward, 1 data-gradient, 2 tap-expanded 1x1 (tiny-Cout 3x3);
+    + 4: three planes per operand (bf16x6)."""
 
     def __init__(self, items):
         import numpy as np
@@ -183,14 +189,16 @@ class PackPlan:
         for i, (w, mode) in enumerate(self.items):
             Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
             assert w.is_contiguous() and w.dtype == torch.float32
-            lc, lk = (9 * Cout, 1) if mode == 2 else (Cout, ks)
-            buf = torch.empty(lib.rfn_packed_weight_size_bf16x3(lc, Cin, lk), device=dev, dtype=torch.float32)
+            lc, lk = (9 * Cout, 1) if (mode & 3) == 2 else (Cout, ks)
+            size_fn = lib.rfn_packed_weight_size_bf16x6 if (mode & 4) else lib.rfn_packed_weight_size_bf16x3
+            buf = torch.empty(size_fn(lc, Cin, lk), device=dev, dtype=torch.float32)
             self.bufs.append(buf)
             rec[i] = (w.data_ptr(), buf.data_ptr(), Cout, Cin, ks, mode)
         self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
 
     def valid_for(self, items):
-        return len(items) == len(self.items) and all(w.data_ptr() == p for (w, _), p in zip(items, self.ptrs))
+        return (len(items) == len(self.items) and all(w.data_ptr() == p for (w, _), p in zip(items, self.ptrs))
+                and all(m == m0 for (_, m), (_, m0) in zip(items, self.items)))
 
     def run(self):
         L.call("rfn_pack_conv_weights_batched_bf16x3", L._c_f(self.table.data_ptr()), _i(len(self.items)))
@@ -270,12 +278,17 @@ def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1
         out1 = torch.empty((N, cout_split, H, W), device=in1.device, dtype=torch.float32)
     o1p, o1ns = L.frames(out1, "out1")
     o2p, o2ns = (None, 0) if out2 is None else L.frames(out2, "out2")
-    b3 = (prec == "bf16x3") if prec is not None else bwd_b3()
-    L.call("rfn_conv2d_fwd_bf16x3" if b3 else "rfn_conv2d_fwd_f32", i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2),
+    prec = prec if prec is not None else ("bf16x3" if bwd_b3() else "f32")
+    b3 = prec == "bf16x3"
+    fn = {"bf16x3": "rfn_conv2d_fwd_bf16x3", "bf16x6": "rfn_conv2d_fwd_bf16x6", "f32": "rfn_conv2d_fwd_f32"}[prec]
+    kname = (_fwd_b3_name(Cout, ks, N, H, W, C1, C2, cout_split, acc1, acc2, ep_mode) if b3 else
+             conv_b3_kernel_name(Cout, ks, N * H * W, None, None, False) + " x6" if prec == "bf16x6" else
+             conv_kernel_name(Cout, ks, N * H * W))
+    L.call(fn, i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2),
            L.dev(wpk), o1p, _l(o1ns), o2p,
            _l(o2ns), _i(Cout), _i(cout_split), _i(1 if acc1 else 0), _i(1 if acc2 else 0), _i(N), _i(H), _i(W), _i(ks),
            _i(ep_mode), L.dev(p0), L.dev(p1), _i(act),
-           meta=("conv", _fwd_b3_name(Cout, ks, N, H, W, C1, C2, cout_split, acc1, acc2, ep_mode) if b3 else conv_kernel_name(Cout, ks, N * H * W),
+           meta=("conv", kname,
                  2.0 * N * H * W * (C1 + C2) * Cout * ks * ks,
                  "N%d %d+%d->%d %dx%d k%d ep%d%s" % (N, C1, C2, Cout, H, W, ks, ep_mode,
                                                   "" if cout_split == Cout else " split"),
@@ -698,7 +711,7 @@ def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk):
     # 3x3 convolutions go through the dense small-map kernels (bf16x3 arithmetic: only where that is allowed)
     dense = k33 and smallmap_conv_ok(H, W, Ch, Cc_, Hd, N)
     dense3 = k33 and smallmap_conv_ok(H, W, Hd, 0, C, N) and not zeros_conv_uses_taps(w3)
-    b3fwd = fp == "bf16x3"
+    b3fwd = fp in ("bf16x3", "bf16x6")  # the caller's pack plan holds forward packs in this map's split arithmetic
     if dense:
         h1 = smallmap_conv(z1, cin2, smallmap_pack(w1, H, W, False), Hd, 1, _f(n1b), _f(n1l), act)
     else:
