@@ -516,11 +516,11 @@ extern "C" int rfn_conv2d_dgrad_act_bf16x3(const float* gin, long gin_ns, int Ci
     return 0;
 }
 
-static thread_local int g_conv_npl = 0;  // set by rfn_conv2d_fwd_bf16x6 around its call of the shared entry point
-extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
-                                     const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
-                                     int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
-                                     const float* p0, const float* p1, int act, rfn_stream_t stream) {
+// shared body of rfn_conv2d_fwd_bf16x3 (npl = 2) and rfn_conv2d_fwd_bf16x6 (npl = 3)
+static int conv2d_fwd_split(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                            const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                            int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
+                            const float* p0, const float* p1, int act, int npl, rfn_stream_t stream) {
     RFN_CHECK_ARG(in1 && wpk && out1 && C1 > 0 && C2 >= 0 && Cout > 0 && N >= 0 && H > 0 && W > 0, -1);
     RFN_CHECK_ARG(ks == 1 || ks == 3, -2);
     RFN_CHECK_ARG(C2 == 0 || in2, -3);
@@ -536,11 +536,18 @@ extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, cons
     p.N = N; p.H = H; p.W = W;
     packed_dims_b3(Cout, C1 + C2, &p.CoutP, &p.Cin8);
     p.ep_mode = ep_mode; p.act = act; p.p0 = p0; p.p1 = p1;
-    p.npl = g_conv_npl;
+    p.npl = npl;
     int rc = dispatch_conv_b3(p, ks, (hipStream_t)stream);
     if (rc) return rc;
     RFN_LAUNCH_CHECK();
     return 0;
+}
+extern "C" int rfn_conv2d_fwd_bf16x3(const float* in1, long in1_ns, int C1, const float* in2, long in2_ns, int C2,
+                                     const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
+                                     int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
+                                     const float* p0, const float* p1, int act, rfn_stream_t stream) {
+    return conv2d_fwd_split(in1, in1_ns, C1, in2, in2_ns, C2, wpk, out1, out1_ns, out2, out2_ns, Cout, cout_split, acc1,
+                            acc2, N, H, W, ks, ep_mode, p0, p1, act, 2, stream);
 }
 // same convolution on three bf16 pieces per operand and six MFMAs per product (24 significant bits, fp32-grade): wpk from
 // rfn_pack_conv_weight_bf16x6
@@ -548,11 +555,8 @@ extern "C" int rfn_conv2d_fwd_bf16x6(const float* in1, long in1_ns, int C1, cons
                                      const float* wpk, float* out1, long out1_ns, float* out2, long out2_ns, int Cout,
                                      int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
                                      const float* p0, const float* p1, int act, rfn_stream_t stream) {
-    g_conv_npl = 3;
-    const int rc = rfn_conv2d_fwd_bf16x3(in1, in1_ns, C1, in2, in2_ns, C2, wpk, out1, out1_ns, out2, out2_ns, Cout,
-                                         cout_split, acc1, acc2, N, H, W, ks, ep_mode, p0, p1, act, stream);
-    g_conv_npl = 0;
-    return rc;
+    return conv2d_fwd_split(in1, in1_ns, C1, in2, in2_ns, C2, wpk, out1, out1_ns, out2, out2_ns, Cout, cout_split, acc1,
+                            acc2, N, H, W, ks, ep_mode, p0, p1, act, 3, stream);
 }
 
 

@@ -577,9 +577,8 @@ static int launch_actnorm_invconv_bwd(const float* x, long x_ns, const float* bi
     if (C == 4 || C == 8) {
         long tot = (long)N * HW;
         // few, fat blocks: every block ends with C*C+2C same-address atomics, which serialise at the memory side
-        static const int cap_env = getenv("RFN_SHELL_BWD_BLOCKS") ? atoi(getenv("RFN_SHELL_BWD_BLOCKS")) : 0;
-        const int cap = cap_env > 0 ? cap_env : 256;
-        int grid = (int)((tot + 255) / 256 < cap ? (tot + 255) / 256 : cap);
+        // (512 / 1024 blocks measured slower: 256-deep same-address atomic chains per accumulator are the budget)
+        int grid = (int)((tot + 255) / 256 < 256 ? (tot + 255) / 256 : 256);
         if (C == 4)
             hipLaunchKernelGGL((actnorm_invconv_bwd_small_kernel<4, TAIL>), dim3(grid), dim3(256), 0, st, x, x_ns, bias,
                                logs, Wm, gz, gz_ns, gx, gx_ns, gW, gbias, glogs, N, HW, tl);
@@ -607,9 +606,7 @@ static int launch_actnorm_invconv_bwd(const float* x, long x_ns, const float* bi
     const int jpt = C * PB / 256;  // channels per thread without a split
     if (ny < jpt / 2) ny = jpt / 2;
     if (ny > 8) ny = 8;
-    static const int ycap_env = getenv("RFN_SHELL_BWD_YCAP") ? atoi(getenv("RFN_SHELL_BWD_YCAP")) : 0;
-    const int ycap = ycap_env > 0 ? ycap_env : 512;  // one wave of workgroups: the y-blocks re-stage the same tile
-    while (ny > 1 && grid * ny > ycap) ny >>= 1;
+    while (ny > 1 && grid * ny > 512) ny >>= 1;  // one wave of workgroups: the y-blocks re-stage the same tile
     hipLaunchKernelGGL(actnorm_invconv_bwd_kernel<TAIL>, dim3(grid, ny), dim3(256), lds, st, x, x_ns, bias, logs, Wm, gz,
                        gz_ns, gx, gx_ns, gW, gbias, glogs, N, C, HW, PB, ntiles, tl);
     return 0;
