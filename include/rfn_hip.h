@@ -288,12 +288,13 @@ int rfn_gauss_sample_f32(const float* o, long o_ns, const float* eps, float* z, 
  * Utils/modules.py:240-244): enc, pri = [B, 2*Z*HW] outputs of the encoder / prior parameter convs (loc half | raw scale
  * half); ps = softplus(pri_raw), es = softplus(enc_raw), pm = pri_loc, em = enc_loc (+ pm when res_q);
  *   zt = pm + ps*eps_p,  zxt = em + es*eps_q,  kl = KL(N(em,es)||N(pm,ps)) element-wise,  em/es also returned.
- * ZHW = Z*H*W.  The backward takes the gradients of the five outputs (any may be NULL) and writes g_enc, g_pri. */
+ * ZHW = Z*H*W.  The backward takes the gradients of the five outputs (any may be NULL) and writes g_enc, g_pri; g_zt and
+ * g_zxt are read with a row stride in floats (>= ZHW), so a channel slice of a wider gradient needs no copy. */
 int rfn_latent_step_fwd_f32(const float* enc, const float* pri, const float* eps_p, const float* eps_q, float* zt,
                             float* zxt, float* kl, float* em, float* es, int B, int ZHW, int res_q, rfn_stream_t stream);
 int rfn_latent_step_bwd_f32(const float* enc, const float* pri, const float* eps_p, const float* eps_q,
-                            const float* g_zt, const float* g_zxt, const float* g_kl, const float* g_em,
-                            const float* g_es, float* g_enc, float* g_pri, int B, int ZHW, int res_q,
+                            const float* g_zt, long g_zt_ns, const float* g_zxt, long g_zxt_ns, const float* g_kl,
+                            const float* g_em, const float* g_es, float* g_enc, float* g_pri, int B, int ZHW, int res_q,
                             rfn_stream_t stream);
 
 /* ---- a10  the per-timestep parameter nets (SimpleParamNet, Utils/modules.py:216-244, called once per frame by
@@ -345,6 +346,19 @@ int rfn_stepbn_bwd_reduce_f32(const float* x, const float* gamma, const float* b
 int rfn_stepbn_bwd_apply_f32(const float* x, const float* beta, const float* g, const float* mean, const float* var,
                              const float* gamma, const float* sg, const float* sgx, float* gx, int S, int B, int C,
                              int HW, float eps, int act, float slope, rfn_stream_t stream);
+/* One BatchNorm layer of the time-batched extractor / upscaler in three launches each way.  Forward: zero + sums + apply;
+ * the apply kernel derives the moments from the sums, writes mean / var [S*C] (kept for the backward) and applies the S
+ * running-statistics updates of the reference's step-wise calls in closed form: run <- decay*run + sum_s coef[s]*stat[s]
+ * (run_mean / run_var [C] both or neither, coef for the mean and coef_u for the unbiased variance are [S] device arrays,
+ * decay = (1-momentum)^S); num_batches_tracked (int64, optional) += S.  acc = scratch [2*S*C].
+ * Backward: zero + per-step sums + apply; sums = scratch [2*S*C]; ggamma / gbeta [C] (both or neither) are written. */
+int rfn_stepbn_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var, float* acc,
+                       float* run_mean, float* run_var, const float* coef, const float* coef_u, float decay,
+                       long long* num_batches_tracked, int S, int B, int C, int HW, float eps, int act, float slope,
+                       rfn_stream_t stream);
+int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const float* beta, const float* g, const float* mean,
+                       const float* var, float* sums, float* gx, float* ggamma, float* gbeta, int S, int B, int C, int HW,
+                       float eps, int act, float slope, rfn_stream_t stream);
 
 /* ---- a9  ConvLSTMLayer.forward gate update  (Utils/modules.py:370-377): cc = conv output [N,4*Hc,HW] in gate order
  * i,f,o,g;  i=σ(cc_i+Wci∘c) f=σ(cc_f+Wcf∘c) g=tanh(cc_g) c'=f∘c+i∘g o=σ(cc_o+Wco∘c') h'=o∘tanh(c').

@@ -121,11 +121,13 @@ class RFN(nn.Module):
             fc = feats_prev
         return fc
 
-    def _deterministic_states(self, feats, n_steps, hprev, cprev, aprev, caprev):
-        """h_t for t = 1..n_steps-1 (RFN_new.py:131-139) and, with smoothing, the backward a_t (:142-153)."""
+    def _deterministic_states(self, feats, n_steps, hprev, cprev, aprev, caprev, x_all=None):
+        """h_t for t = 1..n_steps-1 (RFN_new.py:131-139) and, with smoothing, the backward a_t (:142-153).
+        x_all (optional): the deepest features of frames 0..n_steps-2 as one step-major [n_steps-1, B, ...] tensor."""
         if n_steps < 2:
             return [], [], hprev, cprev
-        x_all = torch.stack([self._last(feats[i - 1]) for i in range(1, n_steps)], 0)  # frames 0..n-2, step-major
+        if x_all is None:
+            x_all = torch.stack([self._last(feats[i - 1]) for i in range(1, n_steps)], 0)  # frames 0..n-2, step-major
         store_ht, hprev, cprev = self.lstm.forward_steps(x_all, hprev, cprev)
         store_at = [None] * (n_steps - 1)
         if self.enable_smoothing:  # runs backward in time over (h_t, features of frame t+1)
@@ -155,11 +157,17 @@ class RFN(nn.Module):
         # extractor on all T frames at once (step-major), BatchNorm statistics per timestep as in the reference
         x_tm = x.transpose(0, 1).reshape(T * B, *x.shape[2:])
         feats_tb = self.extractor.forward_steps(x_tm, T)
+        # the deepest features per step: a step-major view for the ConvLSTM and one unbind for the encoder inputs, so
+        # that their gradients come back as one slice and one stack instead of T zero-fill + copy + add triples
+        last_tb = feats_tb if self.single_feature else feats_tb[-1]
+        last_steps = last_tb.view(T, B, *last_tb.shape[1:])
+        last_t = last_steps.unbind(0)
         if self.single_feature:
-            feats = [feats_tb[i * B:(i + 1) * B] for i in range(T)]
+            feats = list(last_t)
         else:
-            feats = [[f[i * B:(i + 1) * B] for f in feats_tb] for i in range(T)]
-        store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev)
+            feats = [[f[i * B:(i + 1) * B] for f in feats_tb[:-1]] + [last_t[i]] for i in range(T)]
+        x_all = None if self.enable_smoothing else last_steps[:T - 1]
+        store_ht, store_at, _, _ = self._deterministic_states(feats, T, hprev, cprev, aprev, caprev, x_all)
         for j, f in enumerate(feats_tb if not self.single_feature else [feats_tb]):
             DBG.check("feat%d" % j, f)
         DBG.check("ht_last", store_ht[T - 1] if len(store_ht) >= T else store_ht[-1])
@@ -183,8 +191,7 @@ class RFN(nn.Module):
             zt, zxt, kl_t, enc_mean, enc_std = K.LatentStepFn.apply(enc_raw, pri_raw, eps_p, eps_q, self.res_q)
             DBG.check("enc_raw%d" % i, enc_raw); DBG.check("pri_raw%d" % i, pri_raw); DBG.check("zxt%d" % i, zxt)
             st_mean.append(enc_mean); st_std.append(enc_std); st_zx.append(zxprev)
-            hz = torch.cat((ht, zxt), dim=1)
-            base_t.append(hz)
+            base_t.append(zxt)
             if draws is not None:
                 noise_t.append(draws.pop(0).to(dev))
             if self.D == 1:
@@ -193,7 +200,8 @@ class RFN(nn.Module):
 
         # ---- the decoder: all B*(T-1) frames in one call, t-major
         xs = x_tm[B:]
-        base = torch.cat(base_t, dim=0)
+        # base condition cat(h_t, z^x_t) of every step: two time-batched stacks and one channel cat
+        base = torch.cat((torch.cat(store_ht[:T - 1], dim=0), torch.cat(base_t, dim=0)), dim=1)
         # upscaler for all T-1 steps at once; its skip maps are the extractor features of frames 0..T-2
         n1 = (T - 1) * B
         skips = None if self.single_feature else [f[:n1] for f in feats_tb]

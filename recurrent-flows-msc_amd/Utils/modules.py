@@ -115,18 +115,16 @@ def _ema_coef(steps, m, n, device):
 def per_step_batchnorm_act(bn, x, steps, act_code, slope):
     """per_step_batchnorm fused with the following activation on the HIP kernels (rfn_stepbn_*): no permute copies, one
     statistics pass and one normalise+activate pass forward, one reduction and one apply pass backward."""
-    y, mean, var = K.StepBatchNormActFn.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, steps,
-                                              float(bn.eps), act_code, slope)
+    running = None
     if bn.track_running_stats:
-        with torch.no_grad():
-            n = (x.shape[0] // steps) * x.shape[2] * x.shape[3]
-            m = bn.momentum if bn.momentum is not None else 0.1
-            # r <- (1-m) r + m s_t for t = 0..steps-1  ==  (1-m)^S r + Σ_t m (1-m)^(S-1-t) s_t: one addmv per statistic
-            coef, coef_u = _ema_coef(steps, m, n, x.device)
-            decay = (1.0 - m) ** steps
-            bn.running_mean.addmv_(mean.t(), coef, beta=decay)
-            bn.running_var.addmv_(var.t(), coef_u, beta=decay)   # (biased batch variance -> unbiased: factor in coef_u)
-            bn.num_batches_tracked += steps
+        n = (x.shape[0] // steps) * x.shape[2] * x.shape[3]
+        m = bn.momentum if bn.momentum is not None else 0.1
+        # r <- (1-m) r + m s_t for t = 0..steps-1  ==  (1-m)^S r + Σ_t m (1-m)^(S-1-t) s_t, applied by the kernel
+        # (biased batch variance -> unbiased: the factor is in coef_u)
+        coef, coef_u = _ema_coef(steps, m, n, x.device)
+        running = (bn.running_mean, bn.running_var, coef, coef_u, (1.0 - m) ** steps, bn.num_batches_tracked)
+    y, _, _ = K.StepBatchNormActFn.apply(x, bn.weight if bn.affine else None, bn.bias if bn.affine else None, steps,
+                                         float(bn.eps), act_code, slope, running)
     return y
 
 

@@ -1436,11 +1436,57 @@ __global__ void stepbn_finalize_kernel(const float* __restrict__ x, const float*
 }
 // elementwise kernels: VEC = 4 consecutive pixels per thread when HW % 4 == 0 (16-byte accesses); 32-bit index math
 // (the host checks total < 2^31)
+// rfn_stepbn_fwd_f32: the statistics come straight from the stats kernel's sums (no finalize launch); block 0 also writes
+// mean / var for the backward and applies the S running-statistics updates of the step-wise calls in closed form
+struct StepBnFused {
+    const float* acc;      // [S*C][2] shifted sums of stepbn_stats_kernel, or null (mean / var are inputs then)
+    float* mean_out;
+    float* var_out;
+    float* run_mean;       // optional [C]: r <- decay r + sum_s coef[s] mean[s]   (and var with coef_u)
+    float* run_var;
+    const float* coef;
+    const float* coef_u;
+    float decay;
+    long long* nbt;        // optional: += S
+    int S;
+};
+__device__ __forceinline__ void stepbn_moments(const float* __restrict__ x, const float* __restrict__ acc, int sc, int s,
+                                               int c, int B, int C, int HW, float& m, float& v) {
+    const float K = x[((long)s * B * C + c) * HW];
+    const float n = (float)B * HW;
+    const float m1 = acc[2 * sc] / n;
+    m = K + m1;
+    const float vv = acc[2 * sc + 1] / n - m1 * m1;
+    v = vv > 0.f ? vv : 0.f;
+}
 template <int VEC>
 __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
                                     const float* __restrict__ var, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float* __restrict__ y, unsigned total, int B, int C,
-                                    int HW, float eps, int act, float slope) {
+                                    int HW, float eps, int act, float slope, StepBnFused f) {
+    if (f.acc && blockIdx.x == 0) {
+        for (int sc = threadIdx.x; sc < f.S * C; sc += blockDim.x) {
+            float m, v;
+            stepbn_moments(x, f.acc, sc, sc / C, sc % C, B, C, HW, m, v);
+            f.mean_out[sc] = m;
+            f.var_out[sc] = v;
+        }
+        if (f.run_mean) {
+            for (int c = threadIdx.x; c < C; c += blockDim.x) {  // loads only inside the loop: they pipeline
+                float em = 0.f, ev = 0.f;
+#pragma unroll 4
+                for (int s = 0; s < f.S; ++s) {
+                    float m, v;
+                    stepbn_moments(x, f.acc, s * C + c, s, c, B, C, HW, m, v);
+                    em = fmaf(f.coef[s], m, em);
+                    ev = fmaf(f.coef_u[s], v, ev);
+                }
+                f.run_mean[c] = fmaf(f.decay, f.run_mean[c], em);
+                f.run_var[c] = fmaf(f.decay, f.run_var[c], ev);
+            }
+        }
+        if (f.nbt && threadIdx.x == 0) *f.nbt += f.S;
+    }
     const unsigned nvec = total / VEC;
     for (unsigned iv = blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += gridDim.x * blockDim.x) {
         const unsigned idx = iv * VEC;
@@ -1448,7 +1494,14 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
         const int c = (int)(r % (unsigned)C);
         const int s = (int)(r / (unsigned)C / (unsigned)B);
         const int sc = s * C + c;
-        const float rstd = rsqrtf(var[sc] + eps), m = mean[sc];
+        float m, vr;
+        if (f.acc) {
+            stepbn_moments(x, f.acc, sc, s, c, B, C, HW, m, vr);
+        } else {
+            m = mean[sc];
+            vr = var[sc];
+        }
+        const float rstd = rsqrtf(vr + eps);
         const float ga = gamma ? gamma[c] : 1.f, be = gamma ? beta[c] : 0.f;
         float v[VEC];
         if (VEC == 4) {
@@ -1519,7 +1572,18 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
                                         const float* __restrict__ var, const float* __restrict__ gamma,
                                         const float* __restrict__ sg, const float* __restrict__ sgx,
                                         float* __restrict__ gx, unsigned total, int B, int C, int HW, float eps, int act,
-                                        float slope) {
+                                        float slope, float* __restrict__ ggamma, float* __restrict__ gbeta, int S) {
+    if (ggamma && blockIdx.x == 0) {  // parameter gradients = the per-step sums added over the steps
+        for (int c = threadIdx.x; c < C; c += blockDim.x) {
+            float a = 0.f, b = 0.f;
+            for (int st = 0; st < S; ++st) {
+                a += sgx[st * C + c];
+                b += sg[st * C + c];
+            }
+            ggamma[c] = a;
+            gbeta[c] = b;
+        }
+    }
     const float inv_n = 1.f / (float)(B * HW);
     const unsigned nvec = total / VEC;
     for (unsigned iv = blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += gridDim.x * blockDim.x) {
@@ -1576,12 +1640,47 @@ extern "C" int rfn_stepbn_apply_f32(const float* x, const float* mean, const flo
     const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
     const long nthr = v4 ? total / 4 : total;
     const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
+    StepBnFused f;
+    memset(&f, 0, sizeof(f));
     if (v4)
         hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta,
-                           y, (unsigned)total, B, C, HW, eps, act, slope);
+                           y, (unsigned)total, B, C, HW, eps, act, slope, f);
     else
         hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta,
-                           y, (unsigned)total, B, C, HW, eps, act, slope);
+                           y, (unsigned)total, B, C, HW, eps, act, slope, f);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+// stats + normalise + activate + running statistics in three launches (zero, sums, apply): what per_step_batchnorm_act
+// needs of one BatchNorm layer.  mean / var [S*C] are outputs (kept for the backward); run_mean / run_var [C] (both or
+// neither) receive r <- decay r + sum_s coef[s] stat[s] with coef / coef_u [S] on the device; nbt (optional) += S.
+extern "C" int rfn_stepbn_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var,
+                                  float* acc, float* run_mean, float* run_var, const float* coef, const float* coef_u,
+                                  float decay, long long* nbt, int S, int B, int C, int HW, float eps, int act, float slope,
+                                  rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && y && mean && var && acc && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    RFN_CHECK_ARG(((gamma && beta) || (!gamma && !beta)) && ((run_mean && run_var && coef && coef_u) || (!run_mean && !run_var)),
+                  -2);
+    const long total = (long)S * B * C * HW;
+    RFN_CHECK_ARG(total < (1L << 31), -3);
+    hipStream_t st = (hipStream_t)stream;
+    rfn_zero_f32(acc, 2L * S * C, st);
+    int ny = 2048 / (S * C);
+    if (ny < 1) ny = 1;
+    if (ny > B) ny = B;
+    hipLaunchKernelGGL(stepbn_stats_kernel, dim3(S * C, ny), dim3(256), 0, st, x, acc, B, C, HW);
+    StepBnFused f;
+    f.acc = acc; f.mean_out = mean; f.var_out = var; f.run_mean = run_mean; f.run_var = run_var; f.coef = coef;
+    f.coef_u = coef_u; f.decay = decay; f.nbt = nbt; f.S = S;
+    const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    const long nthr = v4 ? total / 4 : total;
+    const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
+    if (v4)
+        hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, y,
+                           (unsigned)total, B, C, HW, eps, act, slope, f);
+    else
+        hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, y,
+                           (unsigned)total, B, C, HW, eps, act, slope, f);
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -1613,10 +1712,40 @@ extern "C" int rfn_stepbn_bwd_apply_f32(const float* x, const float* beta, const
     const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
     if (v4)
         hipLaunchKernelGGL(stepbn_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, g, mean, var,
-                           gamma, sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope);
+                           gamma, sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, nullptr, nullptr, S);
     else
         hipLaunchKernelGGL(stepbn_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, g, mean, var,
-                           gamma, sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope);
+                           gamma, sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, nullptr, nullptr, S);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+// the whole backward of one layer in three launches (zero, per-step sums, apply): sums = scratch [2*S*C] (sg | sgx);
+// ggamma / gbeta [C] (both or neither) = the parameter gradients, written by the apply kernel
+extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const float* beta, const float* g, const float* mean,
+                                  const float* var, float* sums, float* gx, float* ggamma, float* gbeta, int S, int B,
+                                  int C, int HW, float eps, int act, float slope, rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && g && mean && var && sums && gx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    RFN_CHECK_ARG(((gamma && beta) || (!gamma && !beta)) && ((ggamma && gbeta) || (!ggamma && !gbeta)), -2);
+    const long total = (long)S * B * C * HW;
+    RFN_CHECK_ARG(total < (1L << 31), -3);
+    hipStream_t st = (hipStream_t)stream;
+    float* sg = sums;
+    float* sgx = sums + (long)S * C;
+    rfn_zero_f32(sums, 2L * S * C, st);
+    int ny = 2048 / (S * C);
+    if (ny < 1) ny = 1;
+    if (ny > B) ny = B;
+    hipLaunchKernelGGL(stepbn_bwd_reduce_kernel, dim3(S * C, ny), dim3(256), 0, st, x, gamma, beta, g, mean, var, sg, sgx, B,
+                       C, HW, eps, act, slope);
+    const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx) & 15) == 0;
+    const long nthr = v4 ? total / 4 : total;
+    const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
+    if (v4)
+        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, st, x, beta, g, mean, var, gamma, sg, sgx,
+                           gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S);
+    else
+        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, st, x, beta, g, mean, var, gamma, sg, sgx,
+                           gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S);
     RFN_LAUNCH_CHECK();
     return 0;
 }
@@ -1649,7 +1778,8 @@ __global__ void latent_step_fwd_kernel(const float* __restrict__ enc, const floa
 }
 __global__ void latent_step_bwd_kernel(const float* __restrict__ enc, const float* __restrict__ pri,
                                        const float* __restrict__ eps_p, const float* __restrict__ eps_q,
-                                       const float* __restrict__ g_zt, const float* __restrict__ g_zxt,
+                                       const float* __restrict__ g_zt, long g_zt_ns,
+                                       const float* __restrict__ g_zxt, long g_zxt_ns,
                                        const float* __restrict__ g_kl, const float* __restrict__ g_em,
                                        const float* __restrict__ g_es, float* __restrict__ g_enc,
                                        float* __restrict__ g_pri, int B, int ZHW, int res_q) {
@@ -1659,7 +1789,8 @@ __global__ void latent_step_bwd_kernel(const float* __restrict__ enc, const floa
         const float praw = pri[b * 2 * ZHW + ZHW + e], eraw = enc[b * 2 * ZHW + ZHW + e];
         const float pm = pri[b * 2 * ZHW + e], ps = softplusf_(praw), es = softplusf_(eraw);
         const float em = enc[b * 2 * ZHW + e] + (res_q ? pm : 0.f);
-        const float gzt = g_zt ? g_zt[idx] : 0.f, gzx = g_zxt ? g_zxt[idx] : 0.f, gk = g_kl ? g_kl[idx] : 0.f;
+        const float gzt = g_zt ? g_zt[b * g_zt_ns + e] : 0.f, gzx = g_zxt ? g_zxt[b * g_zxt_ns + e] : 0.f;
+        const float gk = g_kl ? g_kl[idx] : 0.f;
         const float ips = 1.f / ps, d = (em - pm) * ips * ips;  // (em-pm)/ps^2
         const float d_em = gzx + gk * d + (g_em ? g_em[idx] : 0.f);
         const float d_es = gzx * eps_q[idx] + gk * (es * ips * ips - 1.f / es) + (g_es ? g_es[idx] : 0.f);
@@ -1685,15 +1816,16 @@ extern "C" int rfn_latent_step_fwd_f32(const float* enc, const float* pri, const
     return 0;
 }
 extern "C" int rfn_latent_step_bwd_f32(const float* enc, const float* pri, const float* eps_p, const float* eps_q,
-                                       const float* g_zt, const float* g_zxt, const float* g_kl, const float* g_em,
-                                       const float* g_es, float* g_enc, float* g_pri, int B, int ZHW, int res_q,
-                                       rfn_stream_t stream) {
+                                       const float* g_zt, long g_zt_ns, const float* g_zxt, long g_zxt_ns,
+                                       const float* g_kl, const float* g_em, const float* g_es, float* g_enc,
+                                       float* g_pri, int B, int ZHW, int res_q, rfn_stream_t stream) {
     RFN_CHECK_ARG(enc && pri && eps_p && eps_q && g_enc && g_pri && B >= 0 && ZHW > 0, -1);
+    RFN_CHECK_ARG((!g_zt || g_zt_ns >= ZHW) && (!g_zxt || g_zxt_ns >= ZHW), -1);
     if (B == 0) return 0;
     long tot = (long)B * ZHW;
     int grid = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);
     hipLaunchKernelGGL(latent_step_bwd_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, enc, pri, eps_p, eps_q,
-                       g_zt, g_zxt, g_kl, g_em, g_es, g_enc, g_pri, B, ZHW, res_q);
+                       g_zt, g_zt_ns, g_zxt, g_zxt_ns, g_kl, g_em, g_es, g_enc, g_pri, B, ZHW, res_q);
     RFN_LAUNCH_CHECK();
     return 0;
 }

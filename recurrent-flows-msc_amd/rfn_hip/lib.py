@@ -82,7 +82,8 @@ SIGNATURES = {
                                _c_s],
     "rfn_gauss_sample_f32": [_c_f, _c_l, _c_f, _c_f, _c_l, ctypes.c_float, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_latent_step_fwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_s],
-    "rfn_latent_step_bwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_s],
+    "rfn_latent_step_bwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i,
+                                _c_s],
     "rfn_smallmap_packed_size": [_c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_smallmap_pack_bf16x3": [_c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_s],
     "rfn_smallmap_dense_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i,
@@ -99,6 +100,10 @@ SIGNATURES = {
                                   _c_i, ctypes.c_float, _c_s],
     "rfn_stepbn_bwd_apply_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i,
                                  ctypes.c_float, _c_i, ctypes.c_float, _c_s],
+    "rfn_stepbn_fwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_float, ctypes.c_void_p,
+                           _c_i, _c_i, _c_i, _c_i, ctypes.c_float, _c_i, ctypes.c_float, _c_s],
+    "rfn_stepbn_bwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float,
+                           _c_i, ctypes.c_float, _c_s],
     "rfn_convlstm_gates_fwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i,
                                    _c_s],
     "rfn_convlstm_gates_bwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f,

@@ -1207,11 +1207,22 @@ class LatentStepFn(torch.autograd.Function):
     def backward(ctx, g_zt, g_zxt, g_kl, g_em, g_es):
         enc, pri, eps_p, eps_q = ctx.saved_tensors
         B, ZHW, res_q = ctx.cfg
+        # g_zt / g_zxt usually arrive as channel slices of the next step's input gradient: read in place (row stride)
+        strided, keep = [], []
+        for g in (g_zt, g_zxt):
+            if g is None:
+                strided += [None, _l(0)]
+                continue
+            if B > 0 and (not g[0].is_contiguous() or (B > 1 and g.stride(0) < ZHW)):
+                g = g.contiguous()
+            keep.append(g)
+            gp, gns = L.frames(g, "g_z")
+            strided += [gp, _l(gns)]
         # keep the contiguous copies alive until the launch is enqueued (a freed temporary's block would be reused)
-        gs = [None if g is None else g.contiguous() for g in (g_zt, g_zxt, g_kl, g_em, g_es)]
+        gs = [None if g is None else g.contiguous() for g in (g_kl, g_em, g_es)]
         g_enc, g_pri = torch.empty_like(enc), torch.empty_like(pri)
-        L.call("rfn_latent_step_bwd_f32", L.dev(enc), L.dev(pri), L.dev(eps_p), L.dev(eps_q), *[L.dev(g) for g in gs],
-               L.dev(g_enc), L.dev(g_pri), _i(B), _i(ZHW), _i(1 if res_q else 0))
+        L.call("rfn_latent_step_bwd_f32", L.dev(enc), L.dev(pri), L.dev(eps_p), L.dev(eps_q), *strided,
+               *[L.dev(g) for g in gs], L.dev(g_enc), L.dev(g_pri), _i(B), _i(ZHW), _i(1 if res_q else 0))
         return g_enc, g_pri, None, None, None
 
 
@@ -1345,11 +1356,14 @@ class ConvLSTMSeqFn(torch.autograd.Function):
 
 class StepBatchNormActFn(torch.autograd.Function):
     """Training-mode BatchNorm2d with per-timestep statistics on a step-major time-batched tensor [S*B, C, H, W],
-    fused with the activation that follows it (rfn_stepbn_*_f32).  Returns (y, mean[S, C], biased var[S, C]); the
-    caller applies the running-statistics EMA.  act: 0 none, 1 relu, 2 leaky_relu(slope), 3 tanh."""
+    fused with the activation that follows it (rfn_stepbn_{fwd,bwd}_f32: three launches each way).  Returns (y, mean[S, C],
+    biased var[S, C]).  act: 0 none, 1 relu, 2 leaky_relu(slope), 3 tanh.  running (optional) = (running_mean, running_var,
+    coef[S], coef_u[S], decay, num_batches_tracked or None): the S exponential-average updates of the step-wise calls,
+    applied by the same launch (r <- decay r + sum_s coef[s] stat[s]); without it the caller does them."""
 
     @staticmethod
-    def forward(ctx, x, gamma, beta, S, eps, act, slope):
+    def forward(ctx, x, gamma, beta, S, eps, act, slope, running=None):
+        ctx.set_materialize_grads(False)  # mean / var are not differentiable: no zero gradients built for them
         x = x.contiguous()
         SB, C, H, W = (int(v) for v in x.shape)
         B, HW = SB // S, H * W
@@ -1359,10 +1373,16 @@ class StepBatchNormActFn(torch.autograd.Function):
         gm = None if gamma is None else gamma.detach().contiguous()
         bt = None if beta is None else beta.detach().contiguous()
         acc = torch.empty((S, C, 2), device=x.device, dtype=torch.float32)  # scratch of the split reduction
-        L.call("rfn_stepbn_stats_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(acc), _i(S), _i(B), _i(C), _i(HW),
-               meta=_shell("stepbn_stats", x, 1))
-        L.call("rfn_stepbn_apply_f32", L.dev(x), L.dev(mean), L.dev(var), L.dev(gm), L.dev(bt), L.dev(y), _i(S), _i(B),
-               _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope), meta=_shell("stepbn_apply", x, 2))
+        rm = rv = cf = cfu = nbt = None
+        decay = 1.0
+        if running is not None:
+            rm, rv, cf, cfu, decay, nbt = running
+            if nbt is not None and (nbt.dtype != torch.int64 or not nbt.is_cuda):
+                raise RuntimeError("num_batches_tracked must be an int64 device tensor")
+        L.call("rfn_stepbn_fwd_f32", L.dev(x), L.dev(gm), L.dev(bt), L.dev(y), L.dev(mean), L.dev(var), L.dev(acc),
+               L.dev(rm), L.dev(rv), L.dev(cf), L.dev(cfu), ctypes.c_float(decay),
+               None if nbt is None else ctypes.c_void_p(nbt.data_ptr()), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps),
+               _i(act), ctypes.c_float(slope), meta=_shell("stepbn_fwd", x, 3))
         ctx.save_for_backward(x, mean, var, gm, bt)
         ctx.cfg = (S, B, C, HW, eps, act, slope, gamma is not None)
         ctx.mark_non_differentiable(mean, var)
@@ -1372,14 +1392,14 @@ class StepBatchNormActFn(torch.autograd.Function):
     def backward(ctx, g, _gm, _gv):
         x, mean, var, gm, bt = ctx.saved_tensors
         S, B, C, HW, eps, act, slope, affine = ctx.cfg
+        if g is None:
+            return (None,) * 8
         g = g.contiguous()
-        sg = torch.empty((S, C), device=x.device, dtype=torch.float32)
-        sgx = torch.empty((S, C), device=x.device, dtype=torch.float32)
+        sums = torch.empty((2, S, C), device=x.device, dtype=torch.float32)
         gx = torch.empty_like(x)
-        L.call("rfn_stepbn_bwd_reduce_f32", L.dev(x), L.dev(gm), L.dev(bt), L.dev(g), L.dev(mean), L.dev(var), L.dev(sg),
-               L.dev(sgx), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
-        L.call("rfn_stepbn_bwd_apply_f32", L.dev(x), L.dev(bt), L.dev(g), L.dev(mean), L.dev(var), L.dev(gm), L.dev(sg),
-               L.dev(sgx), L.dev(gx), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
-        ggamma = sgx.sum(0) if affine else None
-        gbeta = sg.sum(0) if affine else None
-        return gx, ggamma, gbeta, None, None, None, None
+        ggamma = torch.empty((C,), device=x.device, dtype=torch.float32) if affine else None
+        gbeta = torch.empty((C,), device=x.device, dtype=torch.float32) if affine else None
+        L.call("rfn_stepbn_bwd_f32", L.dev(x), L.dev(gm), L.dev(bt), L.dev(g), L.dev(mean), L.dev(var), L.dev(sums),
+               L.dev(gx), L.dev(ggamma), L.dev(gbeta), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act),
+               ctypes.c_float(slope))
+        return gx, ggamma, gbeta, None, None, None, None, None

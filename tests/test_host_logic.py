@@ -32,7 +32,8 @@ def test_c_abi_exports_every_declared_symbol():
     L = lib.load()
     cmap = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "long": ctypes.c_long, "int": ctypes.c_int,
             "float": ctypes.c_float, "rfn_stream_t": ctypes.c_void_p,
-            "const float* const*": ctypes.c_void_p, "float* const*": ctypes.c_void_p}  # host arrays of device pointers
+            "const float* const*": ctypes.c_void_p, "float* const*": ctypes.c_void_p,
+            "long long*": ctypes.c_void_p}  # host arrays of device pointers
     for name, args in protos.items():
         assert hasattr(L, name), "librfn_hip.so does not export %s" % name
         assert name in lib.SIGNATURES, "ctypes binding lacks %s" % name

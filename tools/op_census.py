@@ -31,3 +31,23 @@ for e in prof.key_averages():
 print("---- by op (self device time)")
 for k, v in sorted(tot.items(), key=lambda kv: -kv[1][1])[:40]:
     print("%6d %-50s %9.3f ms" % (v[0], k, v[1]))
+if os.environ.get("STACK"):
+    # second pass: where in this repo do the glue ops come from (forward ops have a Python stack; native autograd
+    # nodes of the backward do not and show up under "<no python frame>")
+    with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stack=True) as prof2:
+        solver.train_step(batches[0])
+        torch.cuda.synchronize()
+    by = {}
+    for e in prof2.key_averages(group_by_stack_n=12):
+        sd = getattr(e, "self_device_time_total", getattr(e, "self_cuda_time_total", 0))
+        if sd <= 0:
+            continue
+        fr = [s for s in e.stack if "recurrent-flows-msc_amd" in s or "bench.py" in s]
+        where = fr[0].split("recurrent-flows-msc_amd/")[-1][:70] if fr else "<no python frame>"
+        k = (e.key, where)
+        c = by.setdefault(k, [0, 0.0])
+        c[0] += e.count
+        c[1] += sd / 1e3
+    print("---- glue ops by source line")
+    for k, v in sorted(by.items(), key=lambda kv: -kv[1][0])[:90]:
+        print("%6d %9.3f ms  %-34s %s" % (v[0], v[1], k[0][:34], k[1]))
