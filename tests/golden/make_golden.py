@@ -330,7 +330,10 @@ def gen_convlstm():
     from Utils import ConvLSTM
     g = torch.Generator().manual_seed(777)
     fx = {}
-    for name, (cin, hc, H, W, B, S) in {"small": (5, 4, 2, 2, 3, 1), "seq3_4x4": (6, 8, 4, 4, 2, 3)}.items():
+    # sibling_8x8: the shape class of the SRNN / VRNN baselines' ConvLSTMs (8x8 maps after three stride-2 convs, input =
+    # cat(frame features, phi_z), SRNN/SRNN.py:161-171, VRNN/VRNN.py:169-173), channel counts scaled down for the fixture
+    for name, (cin, hc, H, W, B, S) in {"small": (5, 4, 2, 2, 3, 1), "seq3_4x4": (6, 8, 4, 4, 2, 3),
+                                        "sibling_8x8": (40, 12, 8, 8, 2, 2)}.items():
         torch.manual_seed(71)
         m = ConvLSTM(cin, hc, [3, 3], bias=True, peephole=True)
         x = torch.randn(B, S, cin, H, W, generator=g, requires_grad=True)

@@ -240,7 +240,7 @@ def test_listglow_time_batching_equals_per_step_calls(golden):
     assert torch.equal(torch.cat(sep).cpu(), tog.cpu())
 
 
-@pytest.mark.parametrize("name", ["small", "seq3_4x4"])
+@pytest.mark.parametrize("name", ["small", "seq3_4x4", "sibling_8x8"])
 def test_convlstm(golden, name):
     from Utils import ConvLSTM
     f = golden("convlstm.pt")[name]
@@ -261,6 +261,40 @@ def test_convlstm(golden, name):
     _, htn, ctn = m(cu(f["x"]), None, None)
     close(htn, f["ht_none"], 1e-5, 1e-6)
     close(ctn, f["ct_none"], 1e-5, 1e-6)
+
+
+@pytest.mark.parametrize("who,cin,hc", [("SRNN lstm_h", 256, 60), ("SRNN lstm_a", 316, 60), ("VRNN lstm", 384, 256)])
+def test_convlstm_at_the_sibling_models_sizes(who, cin, hc):
+    """the SRNN / VRNN baselines drive the same ConvLSTM one frame at a time on 8x8 maps
+    (SRNN/SRNN.py:161-171,210-240: in = 256 or 256 + h_dim, hidden 60; VRNN/VRNN.py:169-173,199-201: in = 256 + 128,
+    hidden 256; defaults of main_srnn.py / main_vrnn.py).  Three recurrent steps with gradients at those channel counts,
+    HIP module against the CPU oracle on the same weights (the golden fixture `sibling_8x8` pins the oracle on this shape
+    class at reduced channel counts)."""
+    from Utils import ConvLSTM
+    torch.manual_seed(91)
+    B, H, W, S = 3, 8, 8, 3
+    m = ConvLSTM(cin, hc, [3, 3], bias=True, peephole=True).cuda()
+    g = torch.Generator().manual_seed(92)
+    xs = [torch.randn(B, 1, cin, H, W, generator=g) for _ in range(S)]
+    h0, c0 = torch.randn(B, hc, H, W, generator=g) * 0.5, torch.randn(B, hc, H, W, generator=g) * 0.5
+    wh, wc = torch.randn(B, hc, H, W, generator=g), torch.randn(B, hc, H, W, generator=g)
+    sd = {k: v.detach().cpu().clone().requires_grad_(v.dtype == torch.float32) for k, v in m.state_dict().items()}
+
+    def run(step, leaf):
+        x = [leaf(t) for t in xs]
+        h, c = leaf(h0), leaf(c0)
+        ht, ct = h, c
+        for t in range(S):
+            _, ht, ct = step(x[t], ht, ct)
+        ((ht * wh.to(ht.device)).sum() + (ct * wc.to(ht.device)).sum()).backward()
+        return ht, ct, x[0].grad, h.grad, c.grad
+    got = run(lambda x, h, c: m(x, h, c), lambda t: t.clone().cuda().requires_grad_(True))
+    want = run(lambda x, h, c: O.convlstm(sd, "", x, h, c), lambda t: t.clone().requires_grad_(True))
+    for name, a, b in zip(["ht", "ct", "grad_x0", "grad_h0", "grad_c0"], got, want):
+        close(a, b, 2e-4, 2e-5)
+    conv = m.LSTMlayer.conv[0]
+    close(conv.weight.grad, sd["LSTMlayer.conv.0.weight"].grad, 2e-3, 2e-4)
+    close(conv.bias.grad, sd["LSTMlayer.conv.0.bias"].grad, 2e-3, 2e-4)
 
 
 @pytest.mark.parametrize("name", ["plain", "smooth_resq", "overshoot_D2", "with_skip", "no_skipfeat"])

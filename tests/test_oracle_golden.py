@@ -198,7 +198,7 @@ def test_listglow_log_prob(golden, name):
     close(xs, f["sample_from_z2"], 1e-3, 1e-4)
 
 
-@pytest.mark.parametrize("name", ["small", "seq3_4x4"])
+@pytest.mark.parametrize("name", ["small", "seq3_4x4", "sibling_8x8"])
 def test_convlstm(golden, name):
     f = golden("convlstm.pt")[name]
     sd = clone_sd(f["sd"], grad=True)
