@@ -55,10 +55,7 @@ def build_solver(B_local, T, device, lr=1e-4, argv=None):
     s.model = RFN(args).to(device).train()
     rdist.broadcast_module_state(s.model)
     s.reducer = rdist.GradBucketReducer(list(s.model.named_parameters()))
-    try:
-        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=lr, fused=True)
-    except Exception:
-        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=lr)
+    s.optimizer = Solver.make_optimizer(s.model.parameters(), lr)
     return s, args
 
 

@@ -375,6 +375,26 @@ int rfn_convlstm_gates_bwd_f32(const float* gates, const float* c_prev, long c_n
                                const float* Wcf, const float* Wco, float* gcc, float* gc_prev, long gcp_ns, int N,
                                int Hc, int HW, rfn_stream_t stream);
 
+/* ---- the optimizer of the training step  (RFN/trainer.py:96: torch.optim.Adam with its defaults; the arithmetic is
+ * torch's: m <- m + (1-b1)(g - m), v <- b2 v + (1-b2) g^2, p <- p - lr/(1-b1^s) * m / (sqrt(v)/sqrt(1-b2^s) + eps), with
+ * g += weight_decay*p first when weight_decay != 0) for ALL parameter tensors in one launch.  `table` and `chunks` are
+ * DEVICE arrays built by the host: one rfn_adam_entry per tensor (s = t - step_offset is that tensor's step count, >= 1)
+ * and one (tensor index, chunk index) int pair per workgroup, a chunk being rfn_adam_chunk_elems() consecutive elements.
+ * p, m, v are updated in place; g is read only.  The hyper-parameters arrive as doubles (Python floats): 1 - beta and the
+ * bias corrections are formed in double and rounded once, the per-element arithmetic is fp32. */
+typedef struct rfn_adam_entry {
+    float* p;
+    const float* g;
+    float* m;
+    float* v;
+    long n;
+    int step_offset;
+    int reserved;
+} rfn_adam_entry;
+int rfn_adam_chunk_elems(void);
+int rfn_adam_step_f32(const rfn_adam_entry* table, const int* chunks, int n_chunks, double lr, double beta1, double beta2,
+                      double eps, double weight_decay, int t, rfn_stream_t stream);
+
 #ifdef __cplusplus
 }
 #endif

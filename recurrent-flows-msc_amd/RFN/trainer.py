@@ -69,11 +69,21 @@ class Solver(object):
         self.model = RFN(self.args).to(self.device)
         rdist.broadcast_module_state(self.model)
         self.reducer = rdist.GradBucketReducer(list(self.model.named_parameters()))
-        self.optimizer = torch.optim.Adam(self.model.parameters(), lr=self.learning_rate)
+        self.optimizer = self.make_optimizer(self.model.parameters(), self.learning_rate)
         self.scheduler = torch.optim.lr_scheduler.ReduceLROnPlateau(self.optimizer, "min", patience=self.patience_lr,
                                                                     factor=self.factor_lr, min_lr=self.min_lr)
         self.earlystopping = EarlyStopping(min_delta=0, patience=self.patience_es, verbose=self.verbose)
         self.counter, self.stop = 0, False
+
+    @staticmethod
+    def make_optimizer(params, lr):
+        """RFN/trainer.py:96: Adam with torch's defaults.  On the GPU the whole update is one launch of the HIP kernel
+        (rfn_hip.optim.HipAdam, same state layout as torch.optim.Adam); CPU parameters only occur in host-logic tests."""
+        params = list(params)
+        if params and params[0].is_cuda:
+            from rfn_hip.optim import HipAdam
+            return HipAdam(params, lr=lr)
+        return torch.optim.Adam(params, lr=lr)
 
     def create_loaders(self):
         if not getattr(self.args, "synthetic_data", False):

@@ -637,6 +637,48 @@ def _tiny_solver_args(path, B=2):
     return args
 
 
+def test_hip_adam_equals_torch_adam():
+    """rfn_adam_step_f32 (all tensors in one launch) against torch.optim.Adam (RFN/trainer.py:96 builds it with defaults):
+    five steps on tensors of awkward sizes, one of which has no gradient on two of the steps (its own step count), then the
+    state dicts are swapped between the two implementations and both continue identically; weight decay covered once."""
+    from rfn_hip.optim import HipAdam
+    g = torch.Generator().manual_seed(3)
+    shapes = [(1,), (7,), (33, 5), (4096,), (8192,), (8193,), (3, 100003), (64, 32, 3, 3)]
+    for wd in (0.0, 0.01):
+        pa = [torch.nn.Parameter(torch.randn(sh, generator=g).cuda()) for sh in shapes]
+        pb = [torch.nn.Parameter(p.detach().clone()) for p in pa]
+        oa = HipAdam(pa, lr=1e-2, weight_decay=wd)
+        ob = torch.optim.Adam(pb, lr=1e-2, weight_decay=wd)
+
+        def step(i, oa, ob, pa, pb):
+            for j, (a, b) in enumerate(zip(pa, pb)):
+                if j == 2 and i in (1, 3):
+                    a.grad = b.grad = None
+                    continue
+                gr = (torch.randn(a.shape, generator=g) * (0.1 + j)).cuda()
+                a.grad, b.grad = gr.clone(), gr.clone()
+            if i == 3:
+                for grp in list(oa.param_groups) + list(ob.param_groups):
+                    grp["lr"] = 3e-3
+            oa.step(); ob.step()
+        for i in range(5):
+            step(i, oa, ob, pa, pb)
+        for a, b in zip(pa, pb):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=2e-6, atol=1e-7)
+        sa, sb = oa.state_dict(), ob.state_dict()
+        for k in sb["state"]:
+            assert float(sa["state"][k]["step"]) == float(sb["state"][k]["step"])
+            torch.testing.assert_close(sa["state"][k]["exp_avg"], sb["state"][k]["exp_avg"], rtol=2e-6, atol=1e-8)
+            torch.testing.assert_close(sa["state"][k]["exp_avg_sq"], sb["state"][k]["exp_avg_sq"], rtol=2e-6, atol=1e-10)
+        # checkpoints are interchangeable: continue each implementation from the other's state
+        oa2, ob2 = HipAdam(pa, lr=3e-3, weight_decay=wd), torch.optim.Adam(pb, lr=3e-3, weight_decay=wd)
+        oa2.load_state_dict(sb); ob2.load_state_dict(sa)
+        for i in range(5, 8):
+            step(i, oa2, ob2, pa, pb)
+        for a, b in zip(pa, pb):
+            torch.testing.assert_close(a.detach(), b.detach(), rtol=4e-6, atol=1e-7)
+
+
 def test_checkpoint_resume_round_trip(tmp_path, conv_precision):
     """Solver.checkpoint -> read_checkpoint (nothing executed from the file) -> Solver.load reproduces the model, the
     optimizer state and the bookkeeping: the same loss on the same batch and identical parameters after one more Adam
@@ -656,7 +698,7 @@ def test_checkpoint_resume_round_trip(tmp_path, conv_precision):
         s.device = torch.device("cuda")
         s.model = RFN(args).cuda().train()
         s.reducer = rdist.GradBucketReducer(list(s.model.named_parameters()))
-        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=1e-3)
+        s.optimizer = Solver.make_optimizer(s.model.parameters(), 1e-3)
         return s
     g = torch.Generator().manual_seed(4)
     x = torch.rand(2, 4, 1, 16, 16, generator=g).cuda()
@@ -753,7 +795,7 @@ def test_training_trajectory_split_precision_vs_fp32_mfma(tmp_path, conv_precisi
         s.device = torch.device("cuda")
         s.model = RFN(args).cuda().train()
         s.reducer = rdist.GradBucketReducer(list(s.model.named_parameters()))
-        s.optimizer = torch.optim.Adam(s.model.parameters(), lr=1e-3)
+        s.optimizer = Solver.make_optimizer(s.model.parameters(), 1e-3)
         for i in range(20):
             torch.manual_seed(100 + i)
             s.train_step(xs[i % 4])

@@ -33,7 +33,8 @@ def test_c_abi_exports_every_declared_symbol():
     cmap = {"const float*": ctypes.c_void_p, "float*": ctypes.c_void_p, "const void*": ctypes.c_void_p, "long": ctypes.c_long, "int": ctypes.c_int,
             "float": ctypes.c_float, "rfn_stream_t": ctypes.c_void_p,
             "const float* const*": ctypes.c_void_p, "float* const*": ctypes.c_void_p,
-            "long long*": ctypes.c_void_p}  # host arrays of device pointers
+            "long long*": ctypes.c_void_p, "const rfn_adam_entry*": ctypes.c_void_p, "const int*": ctypes.c_void_p,
+            "double": ctypes.c_double}  # host arrays of device pointers
     for name, args in protos.items():
         assert hasattr(L, name), "librfn_hip.so does not export %s" % name
         assert name in lib.SIGNATURES, "ctypes binding lacks %s" % name
