@@ -1464,6 +1464,9 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
                                     const float* __restrict__ var, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float* __restrict__ y, unsigned total, int B, int C,
                                     int HW, float eps, int act, float slope, StepBnFused f) {
+    // the launch carries ONE extra workgroup (the first: dispatched first) for the per-layer bookkeeping, so that no
+    // streaming block is delayed by it
+    const unsigned nblk = f.acc ? gridDim.x - 1 : gridDim.x, bid = f.acc ? blockIdx.x - 1 : blockIdx.x;
     if (f.acc && blockIdx.x == 0) {
         for (int sc = threadIdx.x; sc < f.S * C; sc += blockDim.x) {
             float m, v;
@@ -1486,9 +1489,10 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
             }
         }
         if (f.nbt && threadIdx.x == 0) *f.nbt += f.S;
+        return;
     }
     const unsigned nvec = total / VEC;
-    for (unsigned iv = blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += gridDim.x * blockDim.x) {
+    for (unsigned iv = bid * blockDim.x + threadIdx.x; iv < nvec; iv += nblk * blockDim.x) {
         const unsigned idx = iv * VEC;
         const unsigned r = idx / (unsigned)HW;  // frame * C + c
         const int c = (int)(r % (unsigned)C);
@@ -1573,7 +1577,9 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
                                         const float* __restrict__ sg, const float* __restrict__ sgx,
                                         float* __restrict__ gx, unsigned total, int B, int C, int HW, float eps, int act,
                                         float slope, float* __restrict__ ggamma, float* __restrict__ gbeta, int S) {
-    if (ggamma && blockIdx.x == 0) {  // parameter gradients = the per-step sums added over the steps
+    // (one extra workgroup, the first, for the parameter gradients = the per-step sums added over the steps)
+    const unsigned nblk = ggamma ? gridDim.x - 1 : gridDim.x, bid = ggamma ? blockIdx.x - 1 : blockIdx.x;
+    if (ggamma && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float a = 0.f, b = 0.f;
             for (int st = 0; st < S; ++st) {
@@ -1583,10 +1589,11 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
             ggamma[c] = a;
             gbeta[c] = b;
         }
+        return;
     }
     const float inv_n = 1.f / (float)(B * HW);
     const unsigned nvec = total / VEC;
-    for (unsigned iv = blockIdx.x * blockDim.x + threadIdx.x; iv < nvec; iv += gridDim.x * blockDim.x) {
+    for (unsigned iv = bid * blockDim.x + threadIdx.x; iv < nvec; iv += nblk * blockDim.x) {
         const unsigned idx = iv * VEC;
         const unsigned r = idx / (unsigned)HW;
         const int c = (int)(r % (unsigned)C);
@@ -1676,10 +1683,10 @@ extern "C" int rfn_stepbn_fwd_f32(const float* x, const float* gamma, const floa
     const long nthr = v4 ? total / 4 : total;
     const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
     if (v4)
-        hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, y,
+        hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid + 1), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, y,
                            (unsigned)total, B, C, HW, eps, act, slope, f);
     else
-        hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, y,
+        hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid + 1), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, y,
                            (unsigned)total, B, C, HW, eps, act, slope, f);
     RFN_LAUNCH_CHECK();
     return 0;
@@ -1740,12 +1747,13 @@ extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const floa
     const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx) & 15) == 0;
     const long nthr = v4 ? total / 4 : total;
     const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
+    const int extra = ggamma ? 1 : 0;
     if (v4)
-        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, st, x, beta, g, mean, var, gamma, sg, sgx,
-                           gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S);
+        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<4>, dim3(grid + extra), dim3(256), 0, st, x, beta, g, mean, var, gamma,
+                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S);
     else
-        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, st, x, beta, g, mean, var, gamma, sg, sgx,
-                           gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S);
+        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<1>, dim3(grid + extra), dim3(256), 0, st, x, beta, g, mean, var, gamma,
+                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S);
     RFN_LAUNCH_CHECK();
     return 0;
 }
