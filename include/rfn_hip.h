@@ -51,6 +51,19 @@ int rfn_actnorm_invconv_fwd_f32(const float* x, long x_ns, const float* bias, co
 int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const float* bias, const float* logs, const float* Wm,
                                 const float* gz, long gz_ns, float* gx, long gx_ns, float* gW, float* gbias,
                                 float* glogs, int N, int C, int HW, rfn_stream_t stream);
+/* ---- a4  InvConv.get_weight for the K steps of a flow level  (glow_modules.py:178-207, forward direction):
+ *   W[k] = P[k] (lower[k] o tril(-1) + I)(upper[k] o triu(+1) + diag(sign_s[k] * exp(log_s[k]))),  W is [K][C][C];
+ *   *logdet += H*W * sum_k sum(log_s[k])   (float atomics: the caller zeroes it).
+ * The five parameter arguments are HOST arrays of K device pointers (one per step: no stacking copies); K <=
+ * RFN_INVCONV_MAX_STEPS, C <= 64.  Backward: from gW [K][C][C] and gc (gradient of the scalar, may be NULL) to
+ * g_lower, g_upper [K][C][C] (zero outside their triangles) and g_log_s [K][C]. */
+#define RFN_INVCONV_MAX_STEPS 32
+int rfn_invconv_weights_fwd_f32(const float* const* p, const float* const* lower, const float* const* upper,
+                                const float* const* log_s, const float* const* sign_s, float* W, float* logdet, int K,
+                                int C, int HW, rfn_stream_t stream);
+int rfn_invconv_weights_bwd_f32(const float* const* p, const float* const* lower, const float* const* upper,
+                                const float* const* log_s, const float* const* sign_s, const float* gW, const float* gc,
+                                float* g_lower, float* g_upper, float* g_log_s, int K, int C, int HW, rfn_stream_t stream);
 /* reverse direction (glow_modules.py:47-52, 217-221):  x = (Winv · z) * exp(-logs) - bias. */
 int rfn_invconv_actnorm_rev_f32(const float* z, long z_ns, const float* bias, const float* logs, const float* Winv,
                                 float* x, long x_ns, int N, int C, int HW, rfn_stream_t stream);

@@ -152,6 +152,10 @@ class ListGlow(nn.Module):
         ics = [s.invconv for s in steps]
         if not all(ic.LU_decomposed for ic in ics) or any(s.flow_norm == "batchnorm" for s in steps):
             return None, None
+        if K.invconv_weights_ok(ics):  # one launch each way instead of ~17 + ~20 (rfn_invconv_weights_*_f32)
+            return K.InvConvWeightsFn.apply(int(hw), len(ics), *[ic.p for ic in ics], *[ic.sign_s for ic in ics],
+                                            *[ic.lower for ic in ics], *[ic.upper for ic in ics],
+                                            *[ic.log_s for ic in ics])
         lower = torch.stack([ic.lower for ic in ics])
         upper = torch.stack([ic.upper for ic in ics])
         log_s = torch.stack([ic.log_s for ic in ics])

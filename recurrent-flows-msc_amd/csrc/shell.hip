@@ -1758,6 +1758,164 @@ extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const floa
     return 0;
 }
 
+// ------------------------------------------------------------------------------------------------ InvConv.get_weight
+// Flow/glow_modules.py:178-207 for the K steps of a flow level in one launch each way (the reference -- and a torch
+// restatement -- spends ~17 launches per level forward and ~20 backward on this C x C algebra):
+//   Lm = lower o tril(-1) + I,   Um = upper o triu(+1) + diag(sign_s * exp(log_s)),   W = P Lm Um,
+//   dlogdet = HW * sum(log_s)  (summed over the K steps into ONE scalar with float atomics: the caller zeroes it).
+// Backward, given gW and the gradient gc of the scalar:  gT = P^T gW;  g_lower = (gT Um^T) o tril(-1);
+//   g_upper = (Lm^T gT) o triu(+1);  g_log_s = diag(Lm^T gT) * sign_s * exp(log_s) + gc * HW.
+// One workgroup per step, the three matrices in LDS (C <= 64).  Parameters arrive as pointer arrays in the kernel
+// arguments (no stacking copies): K <= RFN_INVCONV_MAX_STEPS.
+struct InvConvWeightsParams {
+    const float* p[RFN_INVCONV_MAX_STEPS];
+    const float* lower[RFN_INVCONV_MAX_STEPS];
+    const float* upper[RFN_INVCONV_MAX_STEPS];
+    const float* log_s[RFN_INVCONV_MAX_STEPS];
+    const float* sign_s[RFN_INVCONV_MAX_STEPS];
+    float* W;            // [K][C][C]
+    float* logdet;       // scalar, accumulated
+    const float* gW;     // backward: [K][C][C]
+    const float* gc;     // backward: gradient of the scalar (may be null)
+    float* g_lower;      // [K][C][C]
+    float* g_upper;      // [K][C][C]
+    float* g_log_s;      // [K][C]
+    int C;
+    float hw;
+};
+// LDS matrices have row stride C + 1: column walks (transposed operands) are bank-conflict free
+__device__ __forceinline__ void invconv_load_LU(const InvConvWeightsParams& q, int k, float* Lm, float* Um) {
+    const int C = q.C, CP = C + 1;
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        Lm[r * CP + c] = r > c ? q.lower[k][i] : (r == c ? 1.f : 0.f);
+        Um[r * CP + c] = r < c ? q.upper[k][i] : (r == c ? q.sign_s[k][r] * expf(q.log_s[k][r]) : 0.f);
+    }
+}
+__device__ __forceinline__ void invconv_load(const float* __restrict__ src, float* dst, int C) {
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) dst[(i / C) * (C + 1) + i % C] = src[i];
+}
+__global__ __launch_bounds__(256) void invconv_weights_fwd_kernel(const InvConvWeightsParams q) {
+    extern __shared__ float sm_iw[];
+    const int C = q.C, CP = C + 1, k = blockIdx.x;
+    float* B0 = sm_iw;            // Lm, then P
+    float* B1 = B0 + C * CP;      // Um
+    float* B2 = B1 + C * CP;      // T = Lm Um
+    invconv_load_LU(q, k, B0, B1);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {  // T = Lm Um (Lm is unit lower triangular: j <= r)
+        const int r = i / C, c = i - r * C;
+        float a = 0.f;
+        for (int j = 0; j <= r; ++j) a = fmaf(B0[r * CP + j], B1[j * CP + c], a);
+        B2[r * CP + c] = a;
+    }
+    __syncthreads();
+    invconv_load(q.p[k], B0, C);
+    __syncthreads();
+    float* W = q.W + (long)k * C * C;
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {  // W = P T
+        const int r = i / C, c = i - r * C;
+        float a = 0.f;
+        for (int j = 0; j < C; ++j) a = fmaf(B0[r * CP + j], B2[j * CP + c], a);
+        W[i] = a;
+    }
+    if (threadIdx.x < 64) {  // one wave: HW * sum(log_s)
+        float v = 0.f;
+        for (int c = threadIdx.x; c < C; c += 64) v += q.log_s[k][c];
+        v = wave_sum(v);
+        if (threadIdx.x == 0) atomicAdd(q.logdet, v * q.hw);
+    }
+}
+__global__ __launch_bounds__(256) void invconv_weights_bwd_kernel(const InvConvWeightsParams q) {
+    extern __shared__ float sm_iw[];
+    const int C = q.C, CP = C + 1, k = blockIdx.x;
+    float* B0 = sm_iw;            // P, then Lm
+    float* B1 = B0 + C * CP;      // gW, then Um
+    float* B2 = B1 + C * CP;      // gT = P^T gW
+    invconv_load(q.p[k], B0, C);
+    invconv_load(q.gW + (long)k * C * C, B1, C);
+    __syncthreads();
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        float a = 0.f;
+        for (int j = 0; j < C; ++j) a = fmaf(B0[j * CP + r], B1[j * CP + c], a);
+        B2[r * CP + c] = a;
+    }
+    __syncthreads();
+    invconv_load_LU(q, k, B0, B1);
+    __syncthreads();
+    const float* Lm = B0;
+    const float* Um = B1;
+    const float* gT = B2;
+    const float gc = q.gc ? q.gc[0] * q.hw : 0.f;
+    float* gl = q.g_lower + (long)k * C * C;
+    float* gu = q.g_upper + (long)k * C * C;
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        float a = 0.f;
+        if (r > c) {          // (gT Um^T)[r][c] = sum_j gT[r][j] Um[c][j]   (Um upper triangular: j >= c)
+            for (int j = c; j < C; ++j) a = fmaf(gT[r * CP + j], Um[c * CP + j], a);
+            gl[i] = a;
+            gu[i] = 0.f;
+        } else {              // (Lm^T gT)[r][c] = sum_j Lm[j][r] gT[j][c]   (Lm unit lower triangular: j >= r)
+            for (int j = r; j < C; ++j) a = fmaf(Lm[j * CP + r], gT[j * CP + c], a);
+            gl[i] = 0.f;
+            if (r < c) {
+                gu[i] = a;
+            } else {
+                gu[i] = 0.f;
+                q.g_log_s[(long)k * C + r] = a * Um[r * CP + r] + gc;
+            }
+        }
+    }
+}
+static int invconv_weights_fill(InvConvWeightsParams& q, const float* const* p, const float* const* lower,
+                                const float* const* upper, const float* const* log_s, const float* const* sign_s, int K,
+                                int C, int HW) {
+    if (!(p && lower && upper && log_s && sign_s && K >= 1 && K <= RFN_INVCONV_MAX_STEPS && C >= 1 && C <= 64 && HW > 0))
+        return -1;
+    memset(&q, 0, sizeof(q));
+    for (int k = 0; k < K; ++k) {
+        if (!(p[k] && lower[k] && upper[k] && log_s[k] && sign_s[k])) return -2;
+        q.p[k] = p[k]; q.lower[k] = lower[k]; q.upper[k] = upper[k]; q.log_s[k] = log_s[k]; q.sign_s[k] = sign_s[k];
+    }
+    q.C = C;
+    q.hw = (float)HW;
+    return 0;
+}
+extern "C" int rfn_invconv_weights_fwd_f32(const float* const* p, const float* const* lower, const float* const* upper,
+                                           const float* const* log_s, const float* const* sign_s, float* W, float* logdet,
+                                           int K, int C, int HW, rfn_stream_t stream) {
+    InvConvWeightsParams q;
+    int rc = invconv_weights_fill(q, p, lower, upper, log_s, sign_s, K, C, HW);
+    if (rc || !W || !logdet) {
+        rfn_set_error("rfn_invconv_weights_fwd_f32: argument check failed (%d)", rc ? rc : -3);
+        return rc ? rc : -3;
+    }
+    q.W = W;
+    q.logdet = logdet;
+    hipLaunchKernelGGL(invconv_weights_fwd_kernel, dim3(K), dim3(256), (size_t)3 * C * (C + 1) * sizeof(float),
+                       (hipStream_t)stream, q);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+extern "C" int rfn_invconv_weights_bwd_f32(const float* const* p, const float* const* lower, const float* const* upper,
+                                           const float* const* log_s, const float* const* sign_s, const float* gW,
+                                           const float* gc, float* g_lower, float* g_upper, float* g_log_s, int K, int C,
+                                           int HW, rfn_stream_t stream) {
+    InvConvWeightsParams q;
+    int rc = invconv_weights_fill(q, p, lower, upper, log_s, sign_s, K, C, HW);
+    if (rc || !gW || !g_lower || !g_upper || !g_log_s) {
+        rfn_set_error("rfn_invconv_weights_bwd_f32: argument check failed (%d)", rc ? rc : -3);
+        return rc ? rc : -3;
+    }
+    q.gW = gW; q.gc = gc; q.g_lower = g_lower; q.g_upper = g_upper; q.g_log_s = g_log_s;
+    hipLaunchKernelGGL(invconv_weights_bwd_kernel, dim3(K), dim3(256), (size_t)3 * C * (C + 1) * sizeof(float),
+                       (hipStream_t)stream, q);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
 // ------------------------------------------------------------------------------------------------ SRNN latent step
 // RFN.loss per timestep (RFN_new.py:167-184,206-207): enc / pri are the outputs [B, 2*Z, HW] of the encoder / prior
 // parameter convs (loc | raw scale, "chunk(2,1)" halves, SimpleParamNet.forward Utils/modules.py:240-244):

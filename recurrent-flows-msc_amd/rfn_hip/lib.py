@@ -26,6 +26,8 @@ SIGNATURES = {
     "rfn_actnorm_invconv_fwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_i, _c_i, _c_i, _c_s],
     "rfn_actnorm_invconv_bwd_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f,
                                     _c_i, _c_i, _c_i, _c_s],
+    "rfn_invconv_weights_fwd_f32": [ctypes.c_void_p] * 5 + [_c_f, _c_f, _c_i, _c_i, _c_i, _c_s],
+    "rfn_invconv_weights_bwd_f32": [ctypes.c_void_p] * 5 + [_c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_s],
     "rfn_invconv_actnorm_rev_f32": [_c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_l, _c_i, _c_i, _c_i, _c_s],
     "rfn_conv2d_fwd_f32": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
                            _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],

@@ -1183,6 +1183,63 @@ def smallmap_conv(in1, in2, packed, Cout, ep_mode=0, p0=None, p1=None, act=0, ou
     return out1
 
 
+INVCONV_MAX_STEPS = 32  # RFN_INVCONV_MAX_STEPS of include/rfn_hip.h
+
+
+def invconv_weights_ok(ics):
+    """the K InvConv layers of a flow level the one-launch kernels take: LU parameterised, on the GPU, C <= 64"""
+    return (0 < len(ics) <= INVCONV_MAX_STEPS and all(ic.LU_decomposed for ic in ics) and ics[0].lower.is_cuda
+            and int(ics[0].lower.shape[0]) <= 64 and os.environ.get("RFN_INVCONV_KERNEL") != "0")
+
+
+class InvConvWeightsFn(torch.autograd.Function):
+    """InvConv.get_weight (glow_modules.py:178-207) of the K steps of a flow level: (W [K, C, C], HW * sum log_s) in one
+    launch, and one launch back to (lower, upper, log_s) gradients (rfn_invconv_weights_{fwd,bwd}_f32).
+    apply(hw, K, p_1..p_K, sign_1..sign_K, lower_1..lower_K, upper_1..upper_K, log_s_1..log_s_K)."""
+
+    @staticmethod
+    def _pointers(P, S, Lw, U, LS):
+        """host arrays of the K device pointers per parameter kind, in the entry points' argument order (the tensors are
+        the modules' own parameters / buffers: dense, alive and at fixed addresses)"""
+        out = []
+        for grp, nm in ((P, "p"), (Lw, "lower"), (U, "upper"), (LS, "log_s"), (S, "sign_s")):
+            for x in grp:
+                L.dev(x, nm)  # fp32, device, contiguous -- raises otherwise
+            out.append(L.ptr_array(list(grp), nm))
+        return out
+
+    @staticmethod
+    def forward(ctx, hw, Kn, *t):
+        ctx.set_materialize_grads(False)
+        P, S, Lw, U, LS = (t[i * Kn:(i + 1) * Kn] for i in range(5))
+        C = int(Lw[0].shape[0])
+        arrs = InvConvWeightsFn._pointers(P, S, Lw, U, LS)
+        W = torch.empty((Kn, C, C), device=Lw[0].device, dtype=torch.float32)
+        c = torch.zeros((), device=Lw[0].device, dtype=torch.float32)
+        L.call("rfn_invconv_weights_fwd_f32", *arrs, L.dev(W), L.dev(c), _i(Kn), _i(C), _i(int(hw)),
+               meta=_shell("invconv_weights_fwd", W, 4))
+        ctx.cfg = (int(hw), Kn, C)
+        ctx.save_for_backward(*t)
+        return W, c
+
+    @staticmethod
+    def backward(ctx, gW, gc):
+        hw, Kn, C = ctx.cfg
+        t = ctx.saved_tensors
+        P, S, Lw, U, LS = (t[i * Kn:(i + 1) * Kn] for i in range(5))
+        dev_ = Lw[0].device
+        if gW is None:
+            gW = torch.zeros((Kn, C, C), device=dev_, dtype=torch.float32)
+        arrs = InvConvWeightsFn._pointers(P, S, Lw, U, LS)
+        gl = torch.empty((Kn, C, C), device=dev_, dtype=torch.float32)
+        gu = torch.empty((Kn, C, C), device=dev_, dtype=torch.float32)
+        gs = torch.empty((Kn, C), device=dev_, dtype=torch.float32)
+        gcc = None if gc is None else gc.contiguous()
+        L.call("rfn_invconv_weights_bwd_f32", *arrs, L.dev(gW.contiguous()), L.dev(gcc), L.dev(gl), L.dev(gu), L.dev(gs),
+               _i(Kn), _i(C), _i(hw), meta=_shell("invconv_weights_bwd", gW, 4))
+        return (None, None) + (None,) * (2 * Kn) + tuple(gl.unbind(0)) + tuple(gu.unbind(0)) + tuple(gs.unbind(0))
+
+
 class LatentStepFn(torch.autograd.Function):
     """one SRNN latent step (RFN_new.py:167-184,206-207): from the raw outputs of the encoder / prior parameter convs
     to (z_t, z^x_t, KL, enc_mean, enc_std) in one kernel each way (rfn_latent_step_{fwd,bwd}_f32)."""

@@ -1099,6 +1099,40 @@ def test_glow_level_node_equals_chain_of_step_nodes(conv_precision, N, C, Cc, S,
         close(a, b.cpu(), 1e-4, 1e-6)
 
 
+@pytest.mark.parametrize("C,Kn,hw", [(4, 10, 1024), (64, 3, 4), (24, 16, 64)])
+def test_invconv_weights_kernel_equals_torch_algebra(conv_precision, C, Kn, hw, monkeypatch):
+    """rfn_invconv_weights_{fwd,bwd}_f32 (InvConv.get_weight of the K steps of a level, glow_modules.py:178-207, in one
+    launch each way) against the batched torch restatement of the same algebra: W, the log-det scalar, and the gradients
+    of lower / upper / log_s for a random gW and scalar gradient."""
+    if conv_precision != "mixed":
+        pytest.skip("arithmetic-independent: run once")
+    from Flow.glow import ListGlow
+    from Flow.glow_modules import InvConv
+    from types import SimpleNamespace
+    torch.manual_seed(60 + C)
+    ics = [InvConv(C, LU_decomposed=True).cuda() for _ in range(Kn)]
+    with torch.no_grad():
+        for ic in ics:  # away from the orthogonal init: generic triangular factors
+            ic.lower.add_(0.3 * torch.randn_like(ic.lower)); ic.upper.add_(0.3 * torch.randn_like(ic.upper))
+            ic.log_s.add_(0.2 * torch.randn_like(ic.log_s))
+    steps = [SimpleNamespace(invconv=ic, flow_norm="actnorm") for ic in ics]
+    g = torch.Generator().manual_seed(61)
+    gW, gc = torch.randn(Kn, C, C, generator=g).cuda(), 1.7
+
+    def run(kernel):
+        monkeypatch.setenv("RFN_INVCONV_KERNEL", "1" if kernel else "0")
+        for ic in ics:
+            ic.zero_grad(set_to_none=True)
+        W, c = ListGlow._batched_invconv(steps, hw)
+        ((W * gW).sum() + gc * c).backward()
+        return [W.detach().clone(), c.detach().clone()] + [p.grad.clone() for ic in ics for p in (ic.lower, ic.upper, ic.log_s)]
+    ref, got = run(False), run(True)
+    for a, b in zip(got, ref):
+        close(a, b.cpu(), 2e-5, 1e-6)
+    # structure: nothing leaks outside the triangles
+    assert float(ics[0].lower.grad.triu().abs().max()) == 0.0 and float(ics[0].upper.grad.tril().abs().max()) == 0.0
+
+
 def test_baseline_config_unconditional_glow_32x32(conv_precision):
     """BASELINE.json configs[1]: unconditional Glow on 32x32x3 images, K=8, L=3 (ListGlow with zero-channel conditions,
     make_conditional=False, learn_prior=False), Hd=256, at its real size: data dependent init + steady-state

@@ -8,7 +8,7 @@ adam = [i for i, r in enumerate(rows) if "adam" in r["Kernel_Name"].lower()]
 clusters = []
 for i in adam:
     ts = int(rows[i]["Start_Timestamp"])
-    if not clusters or ts - clusters[-1][-1][1] > 50e6:
+    if not clusters or ts - clusters[-1][-1][1] > 5e6:
         clusters.append([])
     clusters[-1].append((i, ts))
 s0, s1 = clusters[-2][-1][0] + 1, clusters[-1][-1][0] + 1
