@@ -55,9 +55,10 @@ int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const float* bias, co
  *   W[k] = P[k] (lower[k] o tril(-1) + I)(upper[k] o triu(+1) + diag(sign_s[k] * exp(log_s[k]))),  W is [K][C][C];
  *   *logdet += H*W * sum_k sum(log_s[k])   (float atomics: the caller zeroes it).
  * The five parameter arguments are HOST arrays of K device pointers (one per step: no stacking copies); K <=
- * RFN_INVCONV_MAX_STEPS, C <= 64.  Backward: from gW [K][C][C] and gc (gradient of the scalar, may be NULL) to
+ * RFN_INVCONV_MAX_STEPS, C <= RFN_INVCONV_MAX_CHANNELS (three C x C matrices in LDS).  Backward: from gW [K][C][C] and gc (gradient of the scalar, may be NULL) to
  * g_lower, g_upper [K][C][C] (zero outside their triangles) and g_log_s [K][C]. */
 #define RFN_INVCONV_MAX_STEPS 32
+#define RFN_INVCONV_MAX_CHANNELS 96
 int rfn_invconv_weights_fwd_f32(const float* const* p, const float* const* lower, const float* const* upper,
                                 const float* const* log_s, const float* const* sign_s, float* W, float* logdet, int K,
                                 int C, int HW, rfn_stream_t stream);

@@ -1765,7 +1765,7 @@ extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const floa
 //   dlogdet = HW * sum(log_s)  (summed over the K steps into ONE scalar with float atomics: the caller zeroes it).
 // Backward, given gW and the gradient gc of the scalar:  gT = P^T gW;  g_lower = (gT Um^T) o tril(-1);
 //   g_upper = (Lm^T gT) o triu(+1);  g_log_s = diag(Lm^T gT) * sign_s * exp(log_s) + gc * HW.
-// One workgroup per step, the three matrices in LDS (C <= 64).  Parameters arrive as pointer arrays in the kernel
+// One workgroup per step, the three matrices in LDS (C <= RFN_INVCONV_MAX_CHANNELS).  Parameters arrive as pointer arrays in the kernel
 // arguments (no stacking copies): K <= RFN_INVCONV_MAX_STEPS.
 struct InvConvWeightsParams {
     const float* p[RFN_INVCONV_MAX_STEPS];
@@ -1872,7 +1872,8 @@ __global__ __launch_bounds__(256) void invconv_weights_bwd_kernel(const InvConvW
 static int invconv_weights_fill(InvConvWeightsParams& q, const float* const* p, const float* const* lower,
                                 const float* const* upper, const float* const* log_s, const float* const* sign_s, int K,
                                 int C, int HW) {
-    if (!(p && lower && upper && log_s && sign_s && K >= 1 && K <= RFN_INVCONV_MAX_STEPS && C >= 1 && C <= 64 && HW > 0))
+    if (!(p && lower && upper && log_s && sign_s && K >= 1 && K <= RFN_INVCONV_MAX_STEPS && C >= 1 &&
+          C <= RFN_INVCONV_MAX_CHANNELS && HW > 0))
         return -1;
     memset(&q, 0, sizeof(q));
     for (int k = 0; k < K; ++k) {
@@ -1894,6 +1895,9 @@ extern "C" int rfn_invconv_weights_fwd_f32(const float* const* p, const float* c
     }
     q.W = W;
     q.logdet = logdet;
+    if (C > 64)  // three padded C x C matrices: 112 KB at C = 96 (the LDS of a CU is 160 KB)
+        (void)hipFuncSetAttribute((const void*)invconv_weights_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * C * (C + 1) * (int)sizeof(float));
     hipLaunchKernelGGL(invconv_weights_fwd_kernel, dim3(K), dim3(256), (size_t)3 * C * (C + 1) * sizeof(float),
                        (hipStream_t)stream, q);
     RFN_LAUNCH_CHECK();
@@ -1910,6 +1914,9 @@ extern "C" int rfn_invconv_weights_bwd_f32(const float* const* p, const float* c
         return rc ? rc : -3;
     }
     q.gW = gW; q.gc = gc; q.g_lower = g_lower; q.g_upper = g_upper; q.g_log_s = g_log_s;
+    if (C > 64)
+        (void)hipFuncSetAttribute((const void*)invconv_weights_bwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                  3 * C * (C + 1) * (int)sizeof(float));
     hipLaunchKernelGGL(invconv_weights_bwd_kernel, dim3(K), dim3(256), (size_t)3 * C * (C + 1) * sizeof(float),
                        (hipStream_t)stream, q);
     RFN_LAUNCH_CHECK();

@@ -1183,13 +1183,13 @@ def smallmap_conv(in1, in2, packed, Cout, ep_mode=0, p0=None, p1=None, act=0, ou
     return out1
 
 
-INVCONV_MAX_STEPS = 32  # RFN_INVCONV_MAX_STEPS of include/rfn_hip.h
+INVCONV_MAX_STEPS, INVCONV_MAX_CHANNELS = 32, 96  # RFN_INVCONV_MAX_* of include/rfn_hip.h
 
 
 def invconv_weights_ok(ics):
-    """the K InvConv layers of a flow level the one-launch kernels take: LU parameterised, on the GPU, C <= 64"""
+    """the K InvConv layers of a flow level the one-launch kernels take: LU parameterised, on the GPU, C <= 96"""
     return (0 < len(ics) <= INVCONV_MAX_STEPS and all(ic.LU_decomposed for ic in ics) and ics[0].lower.is_cuda
-            and int(ics[0].lower.shape[0]) <= 64 and os.environ.get("RFN_INVCONV_KERNEL") != "0")
+            and int(ics[0].lower.shape[0]) <= INVCONV_MAX_CHANNELS and os.environ.get("RFN_INVCONV_KERNEL") != "0")
 
 
 class InvConvWeightsFn(torch.autograd.Function):
