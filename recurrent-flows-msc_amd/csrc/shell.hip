@@ -1795,6 +1795,41 @@ __device__ __forceinline__ void invconv_load_LU(const InvConvWeightsParams& q, i
 __device__ __forceinline__ void invconv_load(const float* __restrict__ src, float* dst, int C) {
     for (int i = threadIdx.x; i < C * C; i += blockDim.x) dst[(i / C) * (C + 1) + i % C] = src[i];
 }
+// out(r, c) = sum_j A(r, j) * B(j, c) for the C x C matrices in LDS (row stride C + 1), each thread a 4 x 4 block of the
+// result (8 LDS reads per 16 multiply-adds); TA / TB: the operand is read transposed.  C % 4 == 0 or the scalar tail runs.
+template <bool TA, bool TB, typename Store>
+__device__ __forceinline__ void invconv_mm(const float* __restrict__ A, const float* __restrict__ B, int C, Store store) {
+    const int CP = C + 1, nb = C >> 2;
+    for (int blk = threadIdx.x; blk < nb * nb; blk += blockDim.x) {
+        const int r0 = (blk / nb) * 4, c0 = (blk % nb) * 4;
+        float acc[4][4] = {};
+        for (int j = 0; j < C; ++j) {
+            float av[4], bv[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                av[i] = TA ? A[j * CP + r0 + i] : A[(r0 + i) * CP + j];
+                bv[i] = TB ? B[(c0 + i) * CP + j] : B[j * CP + c0 + i];
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+#pragma unroll
+                for (int k = 0; k < 4; ++k) acc[i][k] = fmaf(av[i], bv[k], acc[i][k]);
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int k = 0; k < 4; ++k) store(r0 + i, c0 + k, acc[i][k]);
+    }
+    const int Cm = nb * 4;  // ragged edge (C % 4 != 0): the last rows and columns one element at a time
+    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
+        const int r = i / C, c = i - r * C;
+        if (r < Cm && c < Cm) continue;
+        float a = 0.f;
+        for (int j = 0; j < C; ++j)
+            a = fmaf(TA ? A[j * CP + r] : A[r * CP + j], TB ? B[c * CP + j] : B[j * CP + c], a);
+        store(r, c, a);
+    }
+}
 __global__ __launch_bounds__(256) void invconv_weights_fwd_kernel(const InvConvWeightsParams q) {
     extern __shared__ float sm_iw[];
     const int C = q.C, CP = C + 1, k = blockIdx.x;
@@ -1803,22 +1838,12 @@ __global__ __launch_bounds__(256) void invconv_weights_fwd_kernel(const InvConvW
     float* B2 = B1 + C * CP;      // T = Lm Um
     invconv_load_LU(q, k, B0, B1);
     __syncthreads();
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {  // T = Lm Um (Lm is unit lower triangular: j <= r)
-        const int r = i / C, c = i - r * C;
-        float a = 0.f;
-        for (int j = 0; j <= r; ++j) a = fmaf(B0[r * CP + j], B1[j * CP + c], a);
-        B2[r * CP + c] = a;
-    }
+    invconv_mm<false, false>(B0, B1, C, [&](int r, int c, float v) { B2[r * CP + c] = v; });
     __syncthreads();
     invconv_load(q.p[k], B0, C);
     __syncthreads();
     float* W = q.W + (long)k * C * C;
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {  // W = P T
-        const int r = i / C, c = i - r * C;
-        float a = 0.f;
-        for (int j = 0; j < C; ++j) a = fmaf(B0[r * CP + j], B2[j * CP + c], a);
-        W[i] = a;
-    }
+    invconv_mm<false, false>(B0, B2, C, [&](int r, int c, float v) { W[r * C + c] = v; });  // W = P T
     if (threadIdx.x < 64) {  // one wave: HW * sum(log_s)
         float v = 0.f;
         for (int c = threadIdx.x; c < C; c += 64) v += q.log_s[k][c];
@@ -1835,39 +1860,21 @@ __global__ __launch_bounds__(256) void invconv_weights_bwd_kernel(const InvConvW
     invconv_load(q.p[k], B0, C);
     invconv_load(q.gW + (long)k * C * C, B1, C);
     __syncthreads();
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
-        const int r = i / C, c = i - r * C;
-        float a = 0.f;
-        for (int j = 0; j < C; ++j) a = fmaf(B0[j * CP + r], B1[j * CP + c], a);
-        B2[r * CP + c] = a;
-    }
+    invconv_mm<true, false>(B0, B1, C, [&](int r, int c, float v) { B2[r * CP + c] = v; });
     __syncthreads();
     invconv_load_LU(q, k, B0, B1);
     __syncthreads();
-    const float* Lm = B0;
     const float* Um = B1;
-    const float* gT = B2;
     const float gc = q.gc ? q.gc[0] * q.hw : 0.f;
     float* gl = q.g_lower + (long)k * C * C;
     float* gu = q.g_upper + (long)k * C * C;
-    for (int i = threadIdx.x; i < C * C; i += blockDim.x) {
-        const int r = i / C, c = i - r * C;
-        float a = 0.f;
-        if (r > c) {          // (gT Um^T)[r][c] = sum_j gT[r][j] Um[c][j]   (Um upper triangular: j >= c)
-            for (int j = c; j < C; ++j) a = fmaf(gT[r * CP + j], Um[c * CP + j], a);
-            gl[i] = a;
-            gu[i] = 0.f;
-        } else {              // (Lm^T gT)[r][c] = sum_j Lm[j][r] gT[j][c]   (Lm unit lower triangular: j >= r)
-            for (int j = r; j < C; ++j) a = fmaf(Lm[j * CP + r], gT[j * CP + c], a);
-            gl[i] = 0.f;
-            if (r < c) {
-                gu[i] = a;
-            } else {
-                gu[i] = 0.f;
-                q.g_log_s[(long)k * C + r] = a * Um[r * CP + r] + gc;
-            }
-        }
-    }
+    float* gs = q.g_log_s + (long)k * C;
+    // g_lower = (gT Um^T) o tril(-1);  g_upper = (Lm^T gT) o triu(+1);  g_log_s from the diagonal of Lm^T gT
+    invconv_mm<false, true>(B2, B1, C, [&](int r, int c, float v) { gl[r * C + c] = r > c ? v : 0.f; });
+    invconv_mm<true, false>(B0, B2, C, [&](int r, int c, float v) {
+        gu[r * C + c] = r < c ? v : 0.f;
+        if (r == c) gs[r] = v * Um[r * CP + r] + gc;
+    });
 }
 static int invconv_weights_fill(InvConvWeightsParams& q, const float* const* p, const float* const* lower,
                                 const float* const* upper, const float* const* log_s, const float* const* sign_s, int K,

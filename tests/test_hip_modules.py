@@ -1099,7 +1099,7 @@ def test_glow_level_node_equals_chain_of_step_nodes(conv_precision, N, C, Cc, S,
         close(a, b.cpu(), 1e-4, 1e-6)
 
 
-@pytest.mark.parametrize("C,Kn,hw", [(4, 10, 1024), (64, 3, 4), (24, 16, 64), (96, 2, 64)])
+@pytest.mark.parametrize("C,Kn,hw", [(4, 10, 1024), (64, 3, 4), (24, 16, 64), (96, 2, 64), (6, 3, 16)])
 def test_invconv_weights_kernel_equals_torch_algebra(conv_precision, C, Kn, hw, monkeypatch):
     """rfn_invconv_weights_{fwd,bwd}_f32 (InvConv.get_weight of the K steps of a level, glow_modules.py:178-207, in one
     launch each way) against the batched torch restatement of the same algebra: W, the log-det scalar, and the gradients
