@@ -1,6 +1,6 @@
 #!/usr/bin/env python3
 """Developer tool: summarise the LAST training step of a rocprofv3 kernel trace (csv) by kernel family."""
-import collections, csv, glob, sys
+import collections, csv, glob, os, sys
 f = (glob.glob(sys.argv[1] + "/*/*kernel_trace.csv") + glob.glob(sys.argv[1] + "/*kernel_trace.csv"))[0]
 rows = list(csv.DictReader(open(f)))
 rows.sort(key=lambda r: int(r["Start_Timestamp"]))
@@ -18,6 +18,8 @@ print("step wall ms %.1f  kernels %d  sum kernel ms %.1f" % ((t1 - t0) / 1e6, le
     int(r["End_Timestamp"]) - int(r["Start_Timestamp"]) for r in seg) / 1e6))
 agg = collections.defaultdict(lambda: [0, 0.0])
 def cat(n):
+    if os.environ.get("TRACE_NO_MERGE") == "1":  # every kernel symbol on its own line (no MINE:shell bucket)
+        return n[:90]
     if "conv_mfma" in n or "wgrad_mfma" in n:
         return "MINE:mfma"
     if any(k in n for k in ("_kernel(float", "pack_weight", "wgrad_finish", "squeeze2d", "gauss", "affine_coupling",
