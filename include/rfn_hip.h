@@ -350,22 +350,14 @@ int rfn_smallmap_conv_bf16x3(const float* in1, long in1_ns, int C1, const float*
  * samples, as the reference's per-timestep calls compute them (RFN_new.py:126-128,191-194).  mean / var (biased) are
  * [S*C]; act: 0 none, 1 relu, 2 leaky_relu(slope), 3 tanh; gamma / beta may both be NULL.  Backward: g' = g*act'(u) with u = xhat*gamma + beta recomputed from x (the output is not read),
  * sg = sum g', sgx = sum g'*xhat per (step, channel), gx = gamma*rstd*(g' - sg/n - xhat*sgx/n). */
-int rfn_stepbn_stats_f32(const float* x, float* mean, float* var, float* acc /* scratch [2*S*C] */, int S, int B, int C,
-                         int HW, rfn_stream_t stream);
-int rfn_stepbn_apply_f32(const float* x, const float* mean, const float* var, const float* gamma, const float* beta,
-                         float* y, int S, int B, int C, int HW, float eps, int act, float slope, rfn_stream_t stream);
-int rfn_stepbn_bwd_reduce_f32(const float* x, const float* gamma, const float* beta, const float* g, const float* mean,
-                              const float* var, float* sg, float* sgx, int S, int B, int C, int HW, float eps, int act,
-                              float slope, rfn_stream_t stream);
-int rfn_stepbn_bwd_apply_f32(const float* x, const float* beta, const float* g, const float* mean, const float* var,
-                             const float* gamma, const float* sg, const float* sgx, float* gx, int S, int B, int C,
-                             int HW, float eps, int act, float slope, rfn_stream_t stream);
-/* One BatchNorm layer of the time-batched extractor / upscaler in three launches each way.  Forward: zero + sums + apply;
- * the apply kernel derives the moments from the sums, writes mean / var [S*C] (kept for the backward) and applies the S
- * running-statistics updates of the reference's step-wise calls in closed form: run <- decay*run + sum_s coef[s]*stat[s]
- * (run_mean / run_var [C] both or neither, coef for the mean and coef_u for the unbiased variance are [S] device arrays,
- * decay = (1-momentum)^S); num_batches_tracked (int64, optional) += S.  acc = scratch [2*S*C].
- * Backward: zero + per-step sums + apply; sums = scratch [2*S*C]; ggamma / gbeta [C] (both or neither) are written. */
+/* One BatchNorm layer of the time-batched extractor / upscaler in two launches each way.  Forward: partial sums + apply;
+ * the apply kernel derives the moments from the partial sums, writes mean / var [S*C] (kept for the backward) and applies
+ * the S running-statistics updates of the reference's step-wise calls in closed form: run <- decay*run + sum_s
+ * coef[s]*stat[s] (run_mean / run_var [C] both or neither, coef for the mean and coef_u for the unbiased variance are [S]
+ * device arrays, decay = (1-momentum)^S); num_batches_tracked (int64, optional) += S.
+ * Backward: per-step partial sums + apply; ggamma / gbeta [C] (both or neither) are written.  acc / sums = scratch of
+ * rfn_stepbn_scratch_floats(S, B, C) floats (no zeroing needed: no atomics, results are deterministic). */
+long rfn_stepbn_scratch_floats(int S, int B, int C);
 int rfn_stepbn_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var, float* acc,
                        float* run_mean, float* run_var, const float* coef, const float* coef_u, float decay,
                        long long* num_batches_tracked, int S, int B, int C, int HW, float eps, int act, float slope,

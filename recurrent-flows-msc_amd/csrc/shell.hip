@@ -1386,7 +1386,15 @@ __device__ __forceinline__ float stepbn_dact(float u, int act, float slope) {  /
     return 1.f;
 }
 // block (sc, j) = frames j, j+gridDim.y, ... of one (step, channel): shifted sums s1 = sum(x-K), s2 = sum((x-K)^2) with
-// K = the pair's first element (keeps the one-pass variance well conditioned); combined by atomics into acc[sc][2]
+// K = the pair's first element (keeps the one-pass variance well conditioned).  Every block stores ITS partial pair at
+// acc[j][sc][2] (no atomics, nothing to zero, deterministic); the consumers add the gridDim.y <= STEPBN_MAX_SPLIT partials.
+constexpr int STEPBN_MAX_SPLIT = 16;
+static int stepbn_split(int S, int B, int C) {  // workgroups per (step, channel): enough blocks for the chip, <= B
+    int ny = 2048 / (S * C);
+    if (ny > STEPBN_MAX_SPLIT) ny = STEPBN_MAX_SPLIT;
+    if (ny > B) ny = B;
+    return ny < 1 ? 1 : ny;
+}
 __global__ __launch_bounds__(256) void stepbn_stats_kernel(const float* __restrict__ x, float* __restrict__ acc, int B,
                                                            int C, int HW) {
     __shared__ float sm[4];
@@ -1418,28 +1426,17 @@ __global__ __launch_bounds__(256) void stepbn_stats_kernel(const float* __restri
     const float ta = block_sum_256(a, sm);
     const float tv = block_sum_256(v, sm);
     if (threadIdx.x == 0) {
-        atomicAdd(&acc[2 * blockIdx.x], ta);
-        atomicAdd(&acc[2 * blockIdx.x + 1], tv);
+        float* dst = acc + ((long)blockIdx.y * gridDim.x + blockIdx.x) * 2;
+        dst[0] = ta;
+        dst[1] = tv;
     }
 }
-__global__ void stepbn_finalize_kernel(const float* __restrict__ x, const float* __restrict__ acc, float* __restrict__ mean,
-                                       float* __restrict__ var, int SC, int B, int C, int HW) {
-    const int sc = blockIdx.x * blockDim.x + threadIdx.x;
-    if (sc >= SC) return;
-    const int s = sc / C, c = sc - s * C;
-    const float K = x[((long)s * B * C + c) * HW];
-    const float n = (float)B * HW;
-    const float m1 = acc[2 * sc] / n;
-    mean[sc] = K + m1;
-    const float vv = acc[2 * sc + 1] / n - m1 * m1;
-    var[sc] = vv > 0.f ? vv : 0.f;
-}
 // elementwise kernels: VEC = 4 consecutive pixels per thread when HW % 4 == 0 (16-byte accesses); 32-bit index math
-// (the host checks total < 2^31)
-// rfn_stepbn_fwd_f32: the statistics come straight from the stats kernel's sums (no finalize launch); block 0 also writes
-// mean / var for the backward and applies the S running-statistics updates of the step-wise calls in closed form
+// (the host checks total < 2^31).  The statistics come straight from the stats kernel's partial sums (no finalize launch);
+// ONE extra workgroup (the first: dispatched first, so no streaming block is delayed by it) writes mean / var for the
+// backward and applies the S running-statistics updates of the step-wise calls in closed form.
 struct StepBnFused {
-    const float* acc;      // [S*C][2] shifted sums of stepbn_stats_kernel, or null (mean / var are inputs then)
+    const float* acc;      // [ny][S*C][2] partial shifted sums of stepbn_stats_kernel
     float* mean_out;
     float* var_out;
     float* run_mean;       // optional [C]: r <- decay r + sum_s coef[s] mean[s]   (and var with coef_u)
@@ -1448,29 +1445,32 @@ struct StepBnFused {
     const float* coef_u;
     float decay;
     long long* nbt;        // optional: += S
-    int S;
+    int S, ny;
 };
 __device__ __forceinline__ void stepbn_moments(const float* __restrict__ x, const float* __restrict__ acc, int sc, int s,
-                                               int c, int B, int C, int HW, float& m, float& v) {
+                                               int c, int B, int C, int HW, int ny, int SC, float& m, float& v) {
     const float K = x[((long)s * B * C + c) * HW];
     const float n = (float)B * HW;
-    const float m1 = acc[2 * sc] / n;
+    float s1 = 0.f, s2 = 0.f;
+    for (int y = 0; y < ny; ++y) {
+        s1 += acc[((long)y * SC + sc) * 2];
+        s2 += acc[((long)y * SC + sc) * 2 + 1];
+    }
+    const float m1 = s1 / n;
     m = K + m1;
-    const float vv = acc[2 * sc + 1] / n - m1 * m1;
+    const float vv = s2 / n - m1 * m1;
     v = vv > 0.f ? vv : 0.f;
 }
 template <int VEC>
-__global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __restrict__ mean,
-                                    const float* __restrict__ var, const float* __restrict__ gamma,
+__global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
                                     const float* __restrict__ beta, float* __restrict__ y, unsigned total, int B, int C,
                                     int HW, float eps, int act, float slope, StepBnFused f) {
-    // the launch carries ONE extra workgroup (the first: dispatched first) for the per-layer bookkeeping, so that no
-    // streaming block is delayed by it
-    const unsigned nblk = f.acc ? gridDim.x - 1 : gridDim.x, bid = f.acc ? blockIdx.x - 1 : blockIdx.x;
-    if (f.acc && blockIdx.x == 0) {
-        for (int sc = threadIdx.x; sc < f.S * C; sc += blockDim.x) {
+    const int SC = f.S * C;
+    const unsigned nblk = gridDim.x - 1, bid = blockIdx.x - 1;
+    if (blockIdx.x == 0) {
+        for (int sc = threadIdx.x; sc < SC; sc += blockDim.x) {
             float m, v;
-            stepbn_moments(x, f.acc, sc, sc / C, sc % C, B, C, HW, m, v);
+            stepbn_moments(x, f.acc, sc, sc / C, sc % C, B, C, HW, f.ny, SC, m, v);
             f.mean_out[sc] = m;
             f.var_out[sc] = v;
         }
@@ -1480,7 +1480,7 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
 #pragma unroll 4
                 for (int s = 0; s < f.S; ++s) {
                     float m, v;
-                    stepbn_moments(x, f.acc, s * C + c, s, c, B, C, HW, m, v);
+                    stepbn_moments(x, f.acc, s * C + c, s, c, B, C, HW, f.ny, SC, m, v);
                     em = fmaf(f.coef[s], m, em);
                     ev = fmaf(f.coef_u[s], v, ev);
                 }
@@ -1497,14 +1497,8 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
         const unsigned r = idx / (unsigned)HW;  // frame * C + c
         const int c = (int)(r % (unsigned)C);
         const int s = (int)(r / (unsigned)C / (unsigned)B);
-        const int sc = s * C + c;
         float m, vr;
-        if (f.acc) {
-            stepbn_moments(x, f.acc, sc, s, c, B, C, HW, m, vr);
-        } else {
-            m = mean[sc];
-            vr = var[sc];
-        }
+        stepbn_moments(x, f.acc, s * C + c, s, c, B, C, HW, f.ny, SC, m, vr);
         const float rstd = rsqrtf(vr + eps);
         const float ga = gamma ? gamma[c] : 1.f, be = gamma ? beta[c] : 0.f;
         float v[VEC];
@@ -1522,7 +1516,8 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
             y[idx] = v[0];
     }
 }
-// block (sc, j): sg += sum g', sgx += sum g' * xhat over frames j, j+gridDim.y, ...  with g' = g * act'(y)
+// block (sc, j): partial sums of g' and g' * xhat over frames j, j+gridDim.y, ...  with g' = g * act'(y), stored at
+// sg[j][sc] / sgx[j][sc] (no atomics, nothing to zero)
 __global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __restrict__ x,
                                                                 const float* __restrict__ gamma,
                                                                 const float* __restrict__ beta,
@@ -1566,8 +1561,8 @@ __global__ __launch_bounds__(256) void stepbn_bwd_reduce_kernel(const float* __r
     const float ta = block_sum_256(a, sm);
     const float tx = block_sum_256(ax, sm);
     if (threadIdx.x == 0) {
-        atomicAdd(&sg[blockIdx.x], ta);
-        atomicAdd(&sgx[blockIdx.x], tx);
+        sg[(long)blockIdx.y * gridDim.x + blockIdx.x] = ta;
+        sgx[(long)blockIdx.y * gridDim.x + blockIdx.x] = tx;
     }
 }
 template <int VEC>
@@ -1576,15 +1571,16 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
                                         const float* __restrict__ var, const float* __restrict__ gamma,
                                         const float* __restrict__ sg, const float* __restrict__ sgx,
                                         float* __restrict__ gx, unsigned total, int B, int C, int HW, float eps, int act,
-                                        float slope, float* __restrict__ ggamma, float* __restrict__ gbeta, int S) {
+                                        float slope, float* __restrict__ ggamma, float* __restrict__ gbeta, int S, int ny) {
     // (one extra workgroup, the first, for the parameter gradients = the per-step sums added over the steps)
+    const int SC = S * C;
     const unsigned nblk = ggamma ? gridDim.x - 1 : gridDim.x, bid = ggamma ? blockIdx.x - 1 : blockIdx.x;
     if (ggamma && blockIdx.x == 0) {
         for (int c = threadIdx.x; c < C; c += blockDim.x) {
             float a = 0.f, b = 0.f;
-            for (int st = 0; st < S; ++st) {
-                a += sgx[st * C + c];
-                b += sg[st * C + c];
+            for (int i = 0; i < ny * S; ++i) {  // [ny][S][C]: all partials of channel c
+                a += sgx[(long)i * C + c];
+                b += sg[(long)i * C + c];
             }
             ggamma[c] = a;
             gbeta[c] = b;
@@ -1601,7 +1597,13 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
         const int sc = s * C + c;
         const float rstd = rsqrtf(var[sc] + eps), m = mean[sc];
         const float w = gamma ? gamma[c] : 1.f, be = gamma ? beta[c] : 0.f;
-        const float k1 = sg[sc] * inv_n, k2 = sgx[sc] * inv_n;
+        float k1 = 0.f, k2 = 0.f;
+        for (int yy = 0; yy < ny; ++yy) {
+            k1 += sg[(long)yy * SC + sc];
+            k2 += sgx[(long)yy * SC + sc];
+        }
+        k1 *= inv_n;
+        k2 *= inv_n;
         float xv[VEC], gv[VEC];
         if (VEC == 4) {
             const float4 t = *reinterpret_cast<const float4*>(x + idx);
@@ -1624,41 +1626,12 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
             gx[idx] = xv[0];
     }
 }
-extern "C" int rfn_stepbn_stats_f32(const float* x, float* mean, float* var, float* acc, int S, int B, int C, int HW,
-                                    rfn_stream_t stream) {
-    RFN_CHECK_ARG(x && mean && var && acc && S > 0 && B > 0 && C > 0 && HW > 0, -1);
-    hipStream_t s = (hipStream_t)stream;
-    rfn_zero_f32(acc, 2L * S * C, s);
-    int ny = 2048 / (S * C);
-    if (ny < 1) ny = 1;
-    if (ny > B) ny = B;
-    hipLaunchKernelGGL(stepbn_stats_kernel, dim3(S * C, ny), dim3(256), 0, s, x, acc, B, C, HW);
-    hipLaunchKernelGGL(stepbn_finalize_kernel, dim3((S * C + 255) / 256), dim3(256), 0, s, x, acc, mean, var, S * C, B, C,
-                       HW);
-    RFN_LAUNCH_CHECK();
-    return 0;
+// floats of scratch rfn_stepbn_fwd_f32 (acc) / rfn_stepbn_bwd_f32 (sums) need for these sizes
+extern "C" long rfn_stepbn_scratch_floats(int S, int B, int C) {
+    if (S <= 0 || B <= 0 || C <= 0) return 0;
+    return 2L * S * C * stepbn_split(S, B, C);
 }
-extern "C" int rfn_stepbn_apply_f32(const float* x, const float* mean, const float* var, const float* gamma,
-                                    const float* beta, float* y, int S, int B, int C, int HW, float eps, int act,
-                                    float slope, rfn_stream_t stream) {
-    RFN_CHECK_ARG(x && mean && var && y && S > 0 && B > 0 && C > 0 && HW > 0 && ((gamma && beta) || (!gamma && !beta)), -1);
-    const long total = (long)S * B * C * HW;
-    RFN_CHECK_ARG(total < (1L << 31), -2);
-    const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
-    const long nthr = v4 ? total / 4 : total;
-    const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
-    StepBnFused f;
-    memset(&f, 0, sizeof(f));
-    if (v4)
-        hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta,
-                           y, (unsigned)total, B, C, HW, eps, act, slope, f);
-    else
-        hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, mean, var, gamma, beta,
-                           y, (unsigned)total, B, C, HW, eps, act, slope, f);
-    RFN_LAUNCH_CHECK();
-    return 0;
-}
-// stats + normalise + activate + running statistics in three launches (zero, sums, apply): what per_step_batchnorm_act
+// stats + normalise + activate + running statistics in TWO launches (partial sums, apply): what per_step_batchnorm_act
 // needs of one BatchNorm layer.  mean / var [S*C] are outputs (kept for the backward); run_mean / run_var [C] (both or
 // neither) receive r <- decay r + sum_s coef[s] stat[s] with coef / coef_u [S] on the device; nbt (optional) += S.
 extern "C" int rfn_stepbn_fwd_f32(const float* x, const float* gamma, const float* beta, float* y, float* mean, float* var,
@@ -1671,63 +1644,26 @@ extern "C" int rfn_stepbn_fwd_f32(const float* x, const float* gamma, const floa
     const long total = (long)S * B * C * HW;
     RFN_CHECK_ARG(total < (1L << 31), -3);
     hipStream_t st = (hipStream_t)stream;
-    rfn_zero_f32(acc, 2L * S * C, st);
-    int ny = 2048 / (S * C);
-    if (ny < 1) ny = 1;
-    if (ny > B) ny = B;
+    const int ny = stepbn_split(S, B, C);
     hipLaunchKernelGGL(stepbn_stats_kernel, dim3(S * C, ny), dim3(256), 0, st, x, acc, B, C, HW);
     StepBnFused f;
     f.acc = acc; f.mean_out = mean; f.var_out = var; f.run_mean = run_mean; f.run_var = run_var; f.coef = coef;
-    f.coef_u = coef_u; f.decay = decay; f.nbt = nbt; f.S = S;
+    f.coef_u = coef_u; f.decay = decay; f.nbt = nbt; f.S = S; f.ny = ny;
     const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
     const long nthr = v4 ? total / 4 : total;
     const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
     if (v4)
-        hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid + 1), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, y,
-                           (unsigned)total, B, C, HW, eps, act, slope, f);
+        hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid + 1), dim3(256), 0, st, x, gamma, beta, y, (unsigned)total, B, C,
+                           HW, eps, act, slope, f);
     else
-        hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid + 1), dim3(256), 0, st, x, nullptr, nullptr, gamma, beta, y,
-                           (unsigned)total, B, C, HW, eps, act, slope, f);
+        hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid + 1), dim3(256), 0, st, x, gamma, beta, y, (unsigned)total, B, C,
+                           HW, eps, act, slope, f);
     RFN_LAUNCH_CHECK();
     return 0;
 }
-extern "C" int rfn_stepbn_bwd_reduce_f32(const float* x, const float* gamma, const float* beta, const float* g,
-                                         const float* mean, const float* var, float* sg, float* sgx, int S, int B, int C,
-                                         int HW, float eps, int act, float slope, rfn_stream_t stream) {
-    RFN_CHECK_ARG(x && g && mean && var && sg && sgx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
-    RFN_CHECK_ARG((gamma && beta) || (!gamma && !beta), -2);
-    rfn_zero_f32(sg, (long)S * C, (hipStream_t)stream);
-    rfn_zero_f32(sgx, (long)S * C, (hipStream_t)stream);
-    int ny = 2048 / (S * C);
-    if (ny < 1) ny = 1;
-    if (ny > B) ny = B;
-    hipLaunchKernelGGL(stepbn_bwd_reduce_kernel, dim3(S * C, ny), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, g, mean,
-                       var, sg, sgx, B, C, HW, eps, act, slope);
-    RFN_LAUNCH_CHECK();
-    return 0;
-}
-extern "C" int rfn_stepbn_bwd_apply_f32(const float* x, const float* beta, const float* g, const float* mean,
-                                        const float* var, const float* gamma, const float* sg, const float* sgx,
-                                        float* gx, int S, int B, int C, int HW, float eps, int act, float slope,
-                                        rfn_stream_t stream) {
-    RFN_CHECK_ARG(x && g && mean && var && sg && sgx && gx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
-    RFN_CHECK_ARG((gamma && beta) || (!gamma && !beta), -2);
-    const long total = (long)S * B * C * HW;
-    RFN_CHECK_ARG(total < (1L << 31), -3);
-    const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx) & 15) == 0;
-    const long nthr = v4 ? total / 4 : total;
-    const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
-    if (v4)
-        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, g, mean, var,
-                           gamma, sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, nullptr, nullptr, S);
-    else
-        hipLaunchKernelGGL(stepbn_bwd_apply_kernel<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream, x, beta, g, mean, var,
-                           gamma, sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, nullptr, nullptr, S);
-    RFN_LAUNCH_CHECK();
-    return 0;
-}
-// the whole backward of one layer in three launches (zero, per-step sums, apply): sums = scratch [2*S*C] (sg | sgx);
-// ggamma / gbeta [C] (both or neither) = the parameter gradients, written by the apply kernel
+// the whole backward of one layer in TWO launches (per-step partial sums, apply): sums = scratch
+// [rfn_stepbn_scratch_floats] (sg | sgx); ggamma / gbeta [C] (both or neither) = the parameter gradients, written by the
+// apply kernel
 extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const float* beta, const float* g, const float* mean,
                                   const float* var, float* sums, float* gx, float* ggamma, float* gbeta, int S, int B,
                                   int C, int HW, float eps, int act, float slope, rfn_stream_t stream) {
@@ -1736,12 +1672,9 @@ extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const floa
     const long total = (long)S * B * C * HW;
     RFN_CHECK_ARG(total < (1L << 31), -3);
     hipStream_t st = (hipStream_t)stream;
+    const int ny = stepbn_split(S, B, C);
     float* sg = sums;
-    float* sgx = sums + (long)S * C;
-    rfn_zero_f32(sums, 2L * S * C, st);
-    int ny = 2048 / (S * C);
-    if (ny < 1) ny = 1;
-    if (ny > B) ny = B;
+    float* sgx = sums + (long)ny * S * C;
     hipLaunchKernelGGL(stepbn_bwd_reduce_kernel, dim3(S * C, ny), dim3(256), 0, st, x, gamma, beta, g, mean, var, sg, sgx, B,
                        C, HW, eps, act, slope);
     const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx) & 15) == 0;
@@ -1750,10 +1683,10 @@ extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const floa
     const int extra = ggamma ? 1 : 0;
     if (v4)
         hipLaunchKernelGGL(stepbn_bwd_apply_kernel<4>, dim3(grid + extra), dim3(256), 0, st, x, beta, g, mean, var, gamma,
-                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S);
+                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S, ny);
     else
         hipLaunchKernelGGL(stepbn_bwd_apply_kernel<1>, dim3(grid + extra), dim3(256), 0, st, x, beta, g, mean, var, gamma,
-                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S);
+                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S, ny);
     RFN_LAUNCH_CHECK();
     return 0;
 }

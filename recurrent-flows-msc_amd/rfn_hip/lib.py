@@ -95,13 +95,7 @@ SIGNATURES = {
                                        _c_i, _c_i, _c_s],
     "rfn_smallmap_conv_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
                                  _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
-    "rfn_stepbn_stats_f32": [_c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_s],
-    "rfn_stepbn_apply_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float, _c_i,
-                             ctypes.c_float, _c_s],
-    "rfn_stepbn_bwd_reduce_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float,
-                                  _c_i, ctypes.c_float, _c_s],
-    "rfn_stepbn_bwd_apply_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i,
-                                 ctypes.c_float, _c_i, ctypes.c_float, _c_s],
+    "rfn_stepbn_scratch_floats": [_c_i, _c_i, _c_i],
     "rfn_stepbn_fwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_float, ctypes.c_void_p,
                            _c_i, _c_i, _c_i, _c_i, ctypes.c_float, _c_i, ctypes.c_float, _c_s],
     "rfn_stepbn_bwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float,
@@ -114,7 +108,7 @@ SIGNATURES = {
     "rfn_convlstm_gates_bwd_f32": [_c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f,
                                    _c_l, _c_i, _c_i, _c_i, _c_s],
 }
-_RESTYPES = {"rfn_last_error": ctypes.c_char_p, "rfn_packed_weight_size": ctypes.c_long,
+_RESTYPES = {"rfn_last_error": ctypes.c_char_p, "rfn_stepbn_scratch_floats": ctypes.c_long, "rfn_packed_weight_size": ctypes.c_long,
              "rfn_packed_weight_size_bf16x3": ctypes.c_long, "rfn_packed_weight_size_bf16x6": ctypes.c_long,
              "rfn_smallmap_packed_size": ctypes.c_long,
              "rfn_coupling_po_packed_bytes": ctypes.c_long}

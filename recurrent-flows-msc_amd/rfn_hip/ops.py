@@ -1413,7 +1413,7 @@ class ConvLSTMSeqFn(torch.autograd.Function):
 
 class StepBatchNormActFn(torch.autograd.Function):
     """Training-mode BatchNorm2d with per-timestep statistics on a step-major time-batched tensor [S*B, C, H, W],
-    fused with the activation that follows it (rfn_stepbn_{fwd,bwd}_f32: three launches each way).  Returns (y, mean[S, C],
+    fused with the activation that follows it (rfn_stepbn_{fwd,bwd}_f32: two launches each way).  Returns (y, mean[S, C],
     biased var[S, C]).  act: 0 none, 1 relu, 2 leaky_relu(slope), 3 tanh.  running (optional) = (running_mean, running_var,
     coef[S], coef_u[S], decay, num_batches_tracked or None): the S exponential-average updates of the step-wise calls,
     applied by the same launch (r <- decay r + sum_s coef[s] stat[s]); without it the caller does them."""
@@ -1429,7 +1429,8 @@ class StepBatchNormActFn(torch.autograd.Function):
         y = torch.empty_like(x)
         gm = None if gamma is None else gamma.detach().contiguous()
         bt = None if beta is None else beta.detach().contiguous()
-        acc = torch.empty((S, C, 2), device=x.device, dtype=torch.float32)  # scratch of the split reduction
+        nscr = int(L.load().rfn_stepbn_scratch_floats(S, B, C))  # partial sums of the split reductions (either way)
+        acc = torch.empty((nscr,), device=x.device, dtype=torch.float32)
         rm = rv = cf = cfu = nbt = None
         decay = 1.0
         if running is not None:
@@ -1441,18 +1442,18 @@ class StepBatchNormActFn(torch.autograd.Function):
                None if nbt is None else ctypes.c_void_p(nbt.data_ptr()), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps),
                _i(act), ctypes.c_float(slope), meta=_shell("stepbn_fwd", x, 3))
         ctx.save_for_backward(x, mean, var, gm, bt)
-        ctx.cfg = (S, B, C, HW, eps, act, slope, gamma is not None)
+        ctx.cfg = (S, B, C, HW, eps, act, slope, gamma is not None, nscr)
         ctx.mark_non_differentiable(mean, var)
         return y, mean, var
 
     @staticmethod
     def backward(ctx, g, _gm, _gv):
         x, mean, var, gm, bt = ctx.saved_tensors
-        S, B, C, HW, eps, act, slope, affine = ctx.cfg
+        S, B, C, HW, eps, act, slope, affine, nscr = ctx.cfg
         if g is None:
             return (None,) * 8
         g = g.contiguous()
-        sums = torch.empty((2, S, C), device=x.device, dtype=torch.float32)
+        sums = torch.empty((nscr,), device=x.device, dtype=torch.float32)
         gx = torch.empty_like(x)
         ggamma = torch.empty((C,), device=x.device, dtype=torch.float32) if affine else None
         gbeta = torch.empty((C,), device=x.device, dtype=torch.float32) if affine else None
