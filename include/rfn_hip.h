@@ -326,13 +326,14 @@ int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float slope_in, co
                               const float* add, int act_out, float slope_out, float* out, float* a_out, int B, int K, int N,
                               int HW, rfn_stream_t stream);
 
-/* Two rfn_smallmap_dense_bf16x3 products (suffix 0 / 1, no `add`) in one launch: the encoder and the prior layer of a
+/* Two rfn_smallmap_dense_bf16x3 products (suffix 0 / 1) in one launch: the encoder and the prior layer of a
  * timestep (RFN_new.py:167-179) have no data dependence on each other.  Same B and HW; K, N per product. */
 int rfn_smallmap_dense_pair_bf16x3(const float* a0, const float* y0, float slope_in0, const float* packed0,
-                                   const float* bias0, int act_out0, float slope_out0, float* out0, float* a_out0, int K0,
-                                   int N0, const float* a1, const float* y1, float slope_in1, const float* packed1,
-                                   const float* bias1, int act_out1, float slope_out1, float* out1, float* a_out1, int K1,
-                                   int N1, int B, int HW, rfn_stream_t stream);
+                                   const float* bias0, const float* add0, int act_out0, float slope_out0, float* out0,
+                                   float* a_out0, int K0, int N0, const float* a1, const float* y1, float slope_in1,
+                                   const float* packed1, const float* bias1, const float* add1, int act_out1,
+                                   float slope_out1, float* out1, float* a_out1, int K1, int N1, int B, int HW,
+                                   rfn_stream_t stream);
 
 /* The same dense product behind the interface of rfn_conv2d_fwd_bf16x3 (ks = 3 implied): N frames of an H x W <= 16
  * map, two-source input, ep_mode 0-3, output channels split at cout_split; acc1 is a bit mask (1: add into out1, 2: add

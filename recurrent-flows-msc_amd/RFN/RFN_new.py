@@ -20,7 +20,7 @@ from Flow.glow_modules import ActNorm
 from rfn_hip import ops as K
 from rfn_hip import debug as DBG
 from Utils import VGG_upscaler, VGG_downscaler, SimpleParamNet, ConvLSTM, free_bits_kl, batch_reduce
-from Utils.modules import recurrent_pair
+from Utils.modules import recurrent_pair, recurrent_pair_split
 
 
 def kl_normal(q_mean, q_std, p_mean, p_std):
@@ -177,14 +177,30 @@ class RFN(nn.Module):
         base_t, noise_t = [], []
         # all 2(T-1) reparameterisation draws of the loop in one launch
         eps_all = None if draws is not None else torch.randn((T - 1, 2) + tuple(zprev.shape), device=dev)
-        both_nets = recurrent_pair(self.encoder, self.prior)  # weight gradients time-batched, layer pairs co-launched
+        # The first conv of the encoder / prior sees cat(static, z) channels, and h_t, a_t and the frame features of every t
+        # are known here: their share of that conv is one time-batched product per net, the per-step launches multiply
+        # the z channels only (Utils.modules.recurrent_pair_split; None -> full inputs through recurrent_pair).
+        h_all = torch.cat(store_ht[:T - 1], dim=0)
+        Ch, Cz = int(h_all.shape[1]), int(zprev.shape[1])
+        if self.enable_smoothing:
+            s_enc = torch.cat(store_at[:T - 1], dim=0)
+            rng_enc = (int(s_enc.shape[1]), int(s_enc.shape[1]) + Cz)
+        else:
+            s_enc = torch.cat((h_all, last_steps[1:T].reshape((T - 1) * B, *last_tb.shape[1:])), dim=1)
+            rng_enc = (Ch, Ch + Cz)
+        split_nets = recurrent_pair_split(self.encoder, s_enc, rng_enc, self.prior, h_all, (Ch, Ch + Cz), T - 1) \
+            if x.is_cuda and torch.is_grad_enabled() else None
+        both_nets = None if split_nets is not None else recurrent_pair(self.encoder, self.prior)
         for i in range(1, T):
             ht = store_ht[i - 1]
-            if self.enable_smoothing:
-                enc_in = torch.cat((store_at[i - 1], zxprev), dim=1)
-            else:
-                enc_in = torch.cat((ht, zxprev, self._last(feats[i])), dim=1)
-            enc_raw, pri_raw = both_nets(enc_in, torch.cat((ht, zxprev if self.res_q else zprev), dim=1))
+            if split_nets is not None:
+                enc_raw, pri_raw = split_nets(i - 1, zxprev, zxprev if self.res_q else zprev)
+            else:  # weight gradients time-batched, layer pairs co-launched
+                if self.enable_smoothing:
+                    enc_in = torch.cat((store_at[i - 1], zxprev), dim=1)
+                else:
+                    enc_in = torch.cat((ht, zxprev, self._last(feats[i])), dim=1)
+                enc_raw, pri_raw = both_nets(enc_in, torch.cat((ht, zxprev if self.res_q else zprev), dim=1))
             # chunk + softplus, res_q shift, both reparameterised draws and the KL in one kernel (RNG order: prior first)
             eps_p = eps_like(zprev) if eps_all is None else eps_all[i - 1, 0]
             eps_q = eps_like(zprev) if eps_all is None else eps_all[i - 1, 1]
@@ -201,7 +217,7 @@ class RFN(nn.Module):
         # ---- the decoder: all B*(T-1) frames in one call, t-major
         xs = x_tm[B:]
         # base condition cat(h_t, z^x_t) of every step: two time-batched stacks and one channel cat
-        base = torch.cat((torch.cat(store_ht[:T - 1], dim=0), torch.cat(base_t, dim=0)), dim=1)
+        base = torch.cat((h_all, torch.cat(base_t, dim=0)), dim=1)
         # upscaler for all T-1 steps at once; its skip maps are the extractor features of frames 0..T-2
         n1 = (T - 1) * B
         skips = None if self.single_feature else [f[:n1] for f in feats_tb]

@@ -349,9 +349,9 @@ class _WeightPort(torch.autograd.Function):
     @staticmethod
     def forward(ctx, w, b, stash):
         ctx.set_materialize_grads(False)
-        ctx.stash = stash
+        ctx.stash, ctx.has_bias = stash, b is not None
         ctx.save_for_backward(w)
-        return w.view_as(w), b.view_as(b)
+        return w.view_as(w), (b.view_as(b) if b is not None else None)
 
     @staticmethod
     def backward(ctx, _gw, _gb):
@@ -359,11 +359,28 @@ class _WeightPort(torch.autograd.Function):
         st = ctx.stash
         if not st.gs:
             return None, None, None
-        X, G = torch.cat(st.xs, 0), torch.cat(st.gs, 0)
+        X = st.xs[0] if len(st.xs) == 1 else torch.cat(st.xs, 0)
+        G = st.gs[0] if len(st.gs) == 1 else torch.cat(st.gs, 0)
         st.xs, st.gs = [], []
-        _, gw, gb = torch.ops.aten.convolution_backward(G, X, w, [w.shape[0]], [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                        [False, True, True])
-        return gw, gb, None
+        _, gw, gb = torch.ops.aten.convolution_backward(G, X, w, [w.shape[0]] if ctx.has_bias else None, [1, 1], [1, 1],
+                                                        [1, 1], False, [0, 0], 1, [False, True, ctx.has_bias])
+        return gw, (gb if ctx.has_bias else None), None
+
+
+class _SplitColumns(torch.autograd.Function):
+    """w [Cout, Cin, k, k] -> (w[:, outside r0:r1], w[:, r0:r1]) as two dense tensors; backward = one cat.  The first conv
+    of the encoder / prior sees cat(static, recurrent) channels: the two column blocks multiply different operands
+    (SimpleParamNet.recurrent_split)."""
+
+    @staticmethod
+    def forward(ctx, w, r0, r1):
+        ctx.rng = (r0, r1)
+        return torch.cat((w[:, :r0], w[:, r1:]), 1), w[:, r0:r1].contiguous()
+
+    @staticmethod
+    def backward(ctx, gs, gr):
+        r0, r1 = ctx.rng
+        return torch.cat((gs[:, :r0], gr, gs[:, r0:]), 1), None, None
 
 
 class _StepConvAct(torch.autograd.Function):
@@ -426,24 +443,28 @@ class _StepDenseActPair(torch.autograd.Function):
     each way (rfn_smallmap_dense_pair_bf16x3)."""
 
     @staticmethod
-    def forward(ctx, x0, w0, b0, st0, slope0, packs0, x1, w1, b1, st1, slope1, packs1):
+    def forward(ctx, x0, w0, b0, st0, slope0, packs0, x1, w1, b1, st1, slope1, packs1, add0=None, add1=None):
+        """add0 / add1 (optional, [B, Cout, H, W]): pre-activation addends -- the time-batched projection of the static
+        input channels of a split first layer; their gradient is the pre-activation gradient"""
         x0, x1 = x0.contiguous(), x1.contiguous()
         y0, y1 = K.smallmap_dense_pair(x0, packs0[0], int(w0.shape[0]), x1, packs1[0], int(w1.shape[0]), bias0=b0, bias1=b1,
-                                       slope_out0=slope0, slope_out1=slope1)
-        ctx.cfg = (st0, slope0, packs0, int(w0.shape[1]), st1, slope1, packs1, int(w1.shape[1]))
+                                       slope_out0=slope0, slope_out1=slope1, add0=add0, add1=add1)
+        ctx.cfg = (st0, slope0, packs0, int(w0.shape[1]), st1, slope1, packs1, int(w1.shape[1]), add0 is not None,
+                   add1 is not None)
         ctx.save_for_backward(x0, y0 if slope0 is not None else None, x1, y1 if slope1 is not None else None)
         return y0, y1
 
     @staticmethod
     def backward(ctx, g0, g1):
         x0, y0, x1, y1 = ctx.saved_tensors
-        st0, slope0, packs0, cin0, st1, slope1, packs1, cin1 = ctx.cfg
+        st0, slope0, packs0, cin0, st1, slope1, packs1, cin1, has0, has1 = ctx.cfg
         g0, g1 = g0.contiguous(), g1.contiguous()
         gx0, gp0, gx1, gp1 = K.smallmap_dense_pair(g0, packs0[1], cin0, g1, packs1[1], cin1, y0=y0, y1=y1,
                                                    slope_in0=slope0 or 0.0, slope_in1=slope1 or 0.0, want_a_out=True)
         st0.xs.append(x0); st0.gs.append(gp0)
         st1.xs.append(x1); st1.gs.append(gp1)
-        return gx0, None, None, None, None, None, gx1, None, None, None, None, None
+        return (gx0, None, None, None, None, None, gx1, None, None, None, None, None, gp0 if has0 else None,
+                gp1 if has1 else None)
 
 
 def recurrent_pair(net0, net1):
@@ -465,6 +486,32 @@ def recurrent_pair(net0, net1):
             w0, b0, st0, s0 = p0[i]
             w1, b1, st1, s1 = p1[i]
             x0, x1 = _StepDenseActPair.apply(x0, w0, b0, st0, s0, k0[i], x1, w1, b1, st1, s1, k1[i])
+        return x0, x1
+    return run
+
+
+def recurrent_pair_split(net0, static0, rng0, net1, static1, rng1, steps):
+    """recurrent_pair for first-layer inputs of the form cat(static channels, recurrent channels) (RFN_new.py:167-179:
+    h_t and the frame features are known for every t before the latent loop, only z is recurrent).  `static` = the static
+    channels of ALL steps, step-major [steps*B, Cs, H, W]; `rng` = (start, stop) of the recurrent channels in the layer's
+    input order.  The static block of the first conv is ONE time-batched product per net before the loop; the per-step
+    launch multiplies the recurrent channels only and adds that projection.  Returns run(t, xr0, xr1) -> (raw0, raw1), or
+    None when the dense small-map path cannot take these nets (the caller then uses recurrent_pair on the full inputs)."""
+    if os.environ.get("RFN_SPLIT_FIRST_LAYER") == "0":
+        return None
+    f0, f1 = net0.recurrent_split(static0, rng0, steps), net1.recurrent_split(static1, rng1, steps)
+    if f0 is None or f1 is None or len(f0.ports) != len(f1.ports):
+        return None
+
+    def run(t, x0, x1):
+        for i in range(len(f0.ports)):
+            w0, b0, st0, s0 = f0.ports[i]
+            w1, b1, st1, s1 = f1.ports[i]
+            if i == 0:
+                x0, x1 = _StepDenseActPair.apply(x0, w0, b0, st0, s0, f0.packs[0], x1, w1, b1, st1, s1, f1.packs[0],
+                                                 f0.proj[t], f1.proj[t])
+            else:
+                x0, x1 = _StepDenseActPair.apply(x0, w0, b0, st0, s0, f0.packs[i], x1, w1, b1, st1, s1, f1.packs[i])
         return x0, x1
     return run
 
@@ -495,10 +542,8 @@ class SimpleParamNet(nn.Module):
         """[B, 2*out, h, w] = (loc | raw scale) before the chunk + softplus of forward()."""
         return self.param_net(self.net(x))
 
-    def recurrent(self, force=False):
-        """A callable equal to `raw` for use once per timestep inside ONE loss evaluation: the weight / bias gradients
-        of all its calls are computed time-batched when the backward pass leaves the recurrence (_WeightPort).  Falls
-        back to `raw` for layer stacks other than [conv3x3 s1, no norm, leaky_relu / relu-free]* (e.g. batchnorm)."""
+    def _recurrent_convs(self, force=False):
+        """[(conv, leaky slope | None)] when the stack is [conv3x3 s1, no norm, leaky_relu]* + param_net, else None"""
         layers = list(self.net)
         ok = torch.is_grad_enabled() and len(layers) % 3 == 0 and (self.param_net.weight.is_cuda or force)
         convs = []
@@ -512,8 +557,50 @@ class SimpleParamNet(nn.Module):
             if ok:
                 convs.append((c, a.net.negative_slope))
         if not ok:
+            return None
+        return convs + [(self.param_net, None)]
+
+    def recurrent_split(self, static_all, rng, steps):
+        """see recurrent_pair_split: an object with .ports [(w, b, stash, slope)] (layer 0 = the recurrent column block),
+        .packs [(forward, data-gradient)] per layer and .proj = the `steps` per-step projections of the static channels
+        through the first conv's static column block; or None when the dense small-map kernels do not apply."""
+        convs = self._recurrent_convs()
+        if convs is None or len(convs) < 2 or not static_all.is_cuda:
+            return None
+        H, W = int(static_all.shape[2]), int(static_all.shape[3])
+        c0 = convs[0][0]
+        r0, r1 = rng
+        Cs, Cr = int(static_all.shape[1]), r1 - r0
+        if (not all(K.smallmap_supported(c, H, W) for c, _ in convs) or Cs + Cr != c0.in_channels or Cs == 0 or Cr <= 0
+                or (Cs * H * W) % 8 or (Cr * H * W) % 8 or static_all.shape[0] % steps):
+            return None
+        B = static_all.shape[0] // steps
+        ws, wr = _SplitColumns.apply(c0.weight, r0, r1)
+        st_s, st_r = _StepStash(), _StepStash()
+        ws_p, _ = _WeightPort.apply(ws, None, st_s)
+        wr_p, b_p = _WeightPort.apply(wr, c0.bias, st_r)
+        ports = [(wr_p, b_p, st_r, convs[0][1])]
+        packs = [(K.smallmap_pack(wr, H, W, False), K.smallmap_pack(wr, H, W, True))]
+        for c, slope in convs[1:]:
+            st = _StepStash()
+            w, b = _WeightPort.apply(c.weight, c.bias, st)
+            ports.append((w, b, st, slope))
+            packs.append((K.smallmap_pack(c.weight, H, W, False), K.smallmap_pack(c.weight, H, W, True)))
+        # all steps' static projection in one product (no bias, no activation: both belong to the per-step launch)
+        proj = _StepDenseAct.apply(static_all, ws_p, None, st_s, None,
+                                   (K.smallmap_pack(ws, H, W, False), K.smallmap_pack(ws, H, W, True)))
+        out = type("SplitRecurrence", (), {})()
+        out.ports, out.packs = ports, packs
+        out.proj = proj.view(steps, B, *proj.shape[1:]).unbind(0)
+        return out
+
+    def recurrent(self, force=False):
+        """A callable equal to `raw` for use once per timestep inside ONE loss evaluation: the weight / bias gradients
+        of all its calls are computed time-batched when the backward pass leaves the recurrence (_WeightPort).  Falls
+        back to `raw` for layer stacks other than [conv3x3 s1, no norm, leaky_relu / relu-free]* (e.g. batchnorm)."""
+        convs = self._recurrent_convs(force)
+        if convs is None:
             return self.raw
-        convs.append((self.param_net, None))
         ports = []
         for c, slope in convs:
             st = _StepStash()

@@ -240,16 +240,16 @@ static int smallmap_fill(SmallmapParams& p, const float* a, const float* y, floa
 
 // rfn_smallmap_dense_bf16x3 twice in one launch (suffix 0 / 1): two products without a data dependence, same B and HW.
 extern "C" int rfn_smallmap_dense_pair_bf16x3(const float* a0, const float* y0, float slope_in0, const float* packed0,
-                                              const float* bias0, int act_out0, float slope_out0, float* out0,
-                                              float* a_out0, int K0, int N0, const float* a1, const float* y1,
-                                              float slope_in1, const float* packed1, const float* bias1, int act_out1,
-                                              float slope_out1, float* out1, float* a_out1, int K1, int N1, int B, int HW,
-                                              rfn_stream_t stream) {
+                                              const float* bias0, const float* add0, int act_out0, float slope_out0,
+                                              float* out0, float* a_out0, int K0, int N0, const float* a1, const float* y1,
+                                              float slope_in1, const float* packed1, const float* bias1, const float* add1,
+                                              int act_out1, float slope_out1, float* out1, float* a_out1, int K1, int N1,
+                                              int B, int HW, rfn_stream_t stream) {
     if (B == 0) return 0;
     SmallmapPair pp;
-    int rc = smallmap_fill(pp.g[0], a0, y0, slope_in0, packed0, bias0, nullptr, act_out0, slope_out0, out0, a_out0, B, K0,
+    int rc = smallmap_fill(pp.g[0], a0, y0, slope_in0, packed0, bias0, add0, act_out0, slope_out0, out0, a_out0, B, K0,
                            N0, HW);
-    if (!rc) rc = smallmap_fill(pp.g[1], a1, y1, slope_in1, packed1, bias1, nullptr, act_out1, slope_out1, out1, a_out1, B,
+    if (!rc) rc = smallmap_fill(pp.g[1], a1, y1, slope_in1, packed1, bias1, add1, act_out1, slope_out1, out1, a_out1, B,
                                 K1, N1, HW);
     if (rc) {
         rfn_set_error("rfn_smallmap_dense_pair_bf16x3: argument check failed (%d)", rc);

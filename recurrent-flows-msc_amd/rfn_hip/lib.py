@@ -90,9 +90,9 @@ SIGNATURES = {
     "rfn_smallmap_pack_bf16x3": [_c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_s],
     "rfn_smallmap_dense_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i,
                                   _c_i, _c_i, _c_i, _c_s],
-    "rfn_smallmap_dense_pair_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i, _c_i,
-                                       _c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i, _c_i,
-                                       _c_i, _c_i, _c_s],
+    "rfn_smallmap_dense_pair_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i,
+                                       _c_i, _c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f,
+                                       _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_smallmap_conv_bf16x3": [_c_f, _c_l, _c_i, _c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i,
                                  _c_i, _c_i, _c_i, _c_f, _c_f, _c_i, _c_s],
     "rfn_stepbn_scratch_floats": [_c_i, _c_i, _c_i],

@@ -1126,9 +1126,9 @@ def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slo
 
 
 def smallmap_dense_pair(a0, packed0, n_ch0, a1, packed1, n_ch1, bias0=None, bias1=None, slope_out0=None, slope_out1=None,
-                        y0=None, y1=None, slope_in0=0.0, slope_in1=0.0, want_a_out=False):
+                        y0=None, y1=None, slope_in0=0.0, slope_in1=0.0, want_a_out=False, add0=None, add1=None):
     """two independent smallmap_dense products in ONE launch (rfn_smallmap_dense_pair_bf16x3): same batch and map size.
-    Returns (out0, out1) or (out0, a0', out1, a1') with want_a_out."""
+    Returns (out0, out1) or (out0, a0', out1, a1') with want_a_out.  add0 / add1: optional [B, n_ch, H, W] addends."""
     a0, a1 = a0.contiguous(), a1.contiguous()
     B, H, W = int(a0.shape[0]), int(a0.shape[2]), int(a0.shape[3])
     assert int(a1.shape[0]) == B and tuple(a1.shape[2:]) == (H, W)
@@ -1140,11 +1140,13 @@ def smallmap_dense_pair(a0, packed0, n_ch0, a1, packed1, n_ch1, bias0=None, bias
     ao1 = torch.empty_like(a1) if want_a_out and y1 is not None else None
     y0c = None if y0 is None else y0.contiguous()  # held until the launch is enqueued
     y1c = None if y1 is None else y1.contiguous()
+    ad0 = None if add0 is None else add0.contiguous()
+    ad1 = None if add1 is None else add1.contiguous()
     fl = ctypes.c_float
     L.call("rfn_smallmap_dense_pair_bf16x3",
-           L.dev(a0), L.dev(y0c), fl(slope_in0), L.dev(packed0), L.dev(bias0), _i(0 if slope_out0 is None else 1),
+           L.dev(a0), L.dev(y0c), fl(slope_in0), L.dev(packed0), L.dev(bias0), L.dev(ad0), _i(0 if slope_out0 is None else 1),
            fl(0.0 if slope_out0 is None else slope_out0), L.dev(out0), L.dev(ao0), _i(K0), _i(n_ch0 * HW),
-           L.dev(a1), L.dev(y1c), fl(slope_in1), L.dev(packed1), L.dev(bias1), _i(0 if slope_out1 is None else 1),
+           L.dev(a1), L.dev(y1c), fl(slope_in1), L.dev(packed1), L.dev(bias1), L.dev(ad1), _i(0 if slope_out1 is None else 1),
            fl(0.0 if slope_out1 is None else slope_out1), L.dev(out1), L.dev(ao1), _i(K1), _i(n_ch1 * HW), _i(B), _i(HW))
     if want_a_out:
         return out0, (ao0 if ao0 is not None else a0), out1, (ao1 if ao1 is not None else a1)
