@@ -6,6 +6,7 @@
   ordinary conv/BN stacks kept as PyTorch-ROCm modules, same constructor arguments and parameter names.
 """
 import os
+from types import SimpleNamespace
 
 import torch
 import torch.nn as nn
@@ -589,10 +590,7 @@ class SimpleParamNet(nn.Module):
         # all steps' static projection in one product (no bias, no activation: both belong to the per-step launch)
         proj = _StepDenseAct.apply(static_all, ws_p, None, st_s, None,
                                    (K.smallmap_pack(ws, H, W, False), K.smallmap_pack(ws, H, W, True)))
-        out = type("SplitRecurrence", (), {})()
-        out.ports, out.packs = ports, packs
-        out.proj = proj.view(steps, B, *proj.shape[1:]).unbind(0)
-        return out
+        return SimpleNamespace(ports=ports, packs=packs, proj=proj.view(steps, B, *proj.shape[1:]).unbind(0))
 
     def recurrent(self, force=False):
         """A callable equal to `raw` for use once per timestep inside ONE loss evaluation: the weight / bias gradients
