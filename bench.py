@@ -86,11 +86,17 @@ def kernel_roofline(rec, steps):
             h["ms"] += ms
             h["flops"] += meta[2]
             h["bytes"] += meta[4]
-    # the roofline line is per kernel SYMBOL, as rocprofv3 --stats groups launches (epilogue variants such as
-    # "+actbwd" are run-time modes of one symbol; the table below keeps them apart)
+    # the roofline line is per kernel TEMPLATE: epilogue variants ("+actbwd": run-time modes of one symbol) and the
+    # tile instantiations of one template ("gemm_wgrad_b3_kernel<2,4,4,2,64>", "<4,2,2,3,64,1>", the grouped forms ...)
+    # are one kernel as far as the question "where does the step's time go" is concerned -- rocprofv3 --stats lists
+    # the instantiations separately, profiles/*_last_step_by_template.txt sums them the same way.  A different arithmetic
+    # of the same template (" x6": six MFMAs per product) has another roof and stays apart.  The table keeps everything.
+    def template_of(k):
+        base = k.split("+")[0]
+        return base.split("<")[0].strip() + (" x6" if base.endswith(" x6") else "")
     syms = {}
     for k, v in groups.items():
-        g = syms.setdefault(k.split("+")[0], {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
+        g = syms.setdefault(template_of(k), {"calls": 0, "ms": 0.0, "flops": 0.0, "bytes": 0.0})
         for f in g:
             g[f] += v[f]
     mfma = {k: v for k, v in syms.items() if v["flops"] > 0}  # (shell kernels carry bytes only)
@@ -276,6 +282,64 @@ def _run_child(extra, env):
     return None, True
 
 
+def launch_ranks(n, argv=None, env=None, timeout=None, script=None):
+    """`python bench.py --gpus N` outside a launcher (no WORLD_SIZE in the environment): this GPU-less parent starts the N
+    ranks itself, one process per GPU, with RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set the way
+    `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1` would set them (backend nccl =
+    RCCL; RFN_DIST_BACKEND / RFN_SINGLE_GPU as documented in DESIGN.md section 8).  Each rank is this same script (its own
+    supervisor + measurement child).  Rank 0's stdout (the ONE JSON line) is passed through; the exit code is the first
+    non-zero exit code of any rank, and when one rank fails the others are terminated instead of waiting for a
+    rendezvous that will never complete.  Nothing here initialises the GPU."""
+    import socket
+    import subprocess
+    argv = list(sys.argv[1:]) if argv is None else list(argv)
+    base_env = dict(os.environ if env is None else env)
+    if "MASTER_PORT" not in base_env:
+        with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as sk:
+            sk.bind(("127.0.0.1", 0))
+            base_env["MASTER_PORT"] = str(sk.getsockname()[1])
+    base_env.setdefault("MASTER_ADDR", "127.0.0.1")
+    base_env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC only on this pool (RCCL peer buffers)
+    procs = []
+    for r in range(n):
+        e = dict(base_env)
+        e.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n),
+                  "GROUP_RANK": "0", "RFN_BENCH_SELF_LAUNCHED": "1"})
+        procs.append(subprocess.Popen([sys.executable, script or os.path.abspath(__file__)] + argv, env=e,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc, t0 = 0, time.time()
+    live = set(range(n))
+    while live:
+        for r in sorted(live):
+            c = procs[r].poll()
+            if c is None:
+                continue
+            live.discard(r)
+            if c != 0 and rc == 0:
+                rc = c
+                print("[bench] rank %d exited with code %d; stopping the other ranks" % (r, c), file=sys.stderr, flush=True)
+        if live and (rc != 0 or (timeout is not None and time.time() - t0 > timeout)):
+            rc = rc or 124
+            for r in live:
+                procs[r].terminate()
+            for r in live:
+                try:
+                    procs[r].wait(timeout=20)
+                except subprocess.TimeoutExpired:
+                    procs[r].kill()
+            break
+        if live:
+            time.sleep(0.2)
+    out0 = procs[0].stdout.read() if procs[0].stdout else ""
+    lines = [l for l in out0.splitlines() if l.startswith("{")]
+    if rc == 0 and not lines:
+        print("[bench] rank 0 printed no JSON line", file=sys.stderr, flush=True)
+        rc = 1
+    if lines:
+        print(lines[-1], flush=True)
+    return rc
+
+
 def supervise():
     """The parent never touches the GPU.  It runs the measurement once per convolution arithmetic (RFN_CONV_PRECISION =
     mixed, bf16x3, f32), each in a fresh child process, and prints ONE line holding all of them.  The headline (`value`,
@@ -355,6 +419,8 @@ def main():
         # RFN_DIST_BACKEND=gloo + RFN_SINGLE_GPU=1: rehearsal of the N>1 path on a one-GPU box (all ranks on cuda:0)
         import datetime
         dist.init_process_group(os.environ.get("RFN_DIST_BACKEND", "nccl"), timeout=datetime.timedelta(seconds=300))
+    assert world == a.gpus or "--gpus" not in " ".join(sys.argv), \
+        "--gpus %d but WORLD_SIZE=%d: launch with --nproc-per-node equal to --gpus" % (a.gpus, world)
     assert a.batch % world == 0, "global batch must divide over ranks"
     B_local = a.batch // world
 
@@ -380,6 +446,11 @@ def main():
             solver.train_step(batches[i % 2])
         torch.cuda.synchronize()
         rec, rlib.PROFILE = rlib.PROFILE, None
+    else:
+        # same number of optimizer steps in every run, profiled or not, so that `bits_per_dim_last_step` is comparable
+        # between the arithmetics of `precision_runs` (and between N = 1 and N > 1)
+        for i in range(2):
+            solver.train_step(batches[i % 2])
     graphed = False
     if not a.no_graph:
         graphed = solver.capture_graph(batches[0])
@@ -459,8 +530,19 @@ def main():
         dist.destroy_process_group()
 
 
+def _gpus_arg(argv):
+    for i, a in enumerate(argv):
+        if a == "--gpus" and i + 1 < len(argv):
+            return int(argv[i + 1])
+        if a.startswith("--gpus="):
+            return int(a.split("=", 1)[1])
+    return 1
+
+
 if __name__ == "__main__":
     if "--child" in sys.argv or os.environ.get("RFN_BENCH_NO_SUPERVISOR") == "1":
         main()
+    elif "WORLD_SIZE" not in os.environ and _gpus_arg(sys.argv[1:]) > 1:
+        sys.exit(launch_ranks(_gpus_arg(sys.argv[1:])))   # the driver's `python bench.py --gpus N` form
     else:
         sys.exit(supervise())

@@ -268,6 +268,7 @@ class Solver(object):
             epoch_loss = float(np.mean(self.losses)) if self.losses else math.nan
             # every rank must take the same decisions (checkpoint value, early stop, plateau scheduler): rank-local
             # losses would let learning rates diverge or leave one rank waiting in an all-reduce the others never enter
+            # (host scalars: all_reduce_mean_scalars moves them to the GPU when the group is RCCL-only)
             epoch_loss, stop_flag = rdist.all_reduce_mean_scalars(torch.tensor(epoch_loss), torch.tensor(float(self.stop)))
             self.stop = stop_flag > 0.0
             self.checkpoint("rfn.pt", self.epoch_i, epoch_loss)   # (collective: gathers the sharded initial states)
@@ -290,16 +291,36 @@ class Solver(object):
         the same Namespace as a plain dict.  Collective under data parallelism: the batch-sharded initial states are
         gathered so that the file holds the GLOBAL batch rows (a single process can resume it); rank 0 writes."""
         state = rdist.gather_sharded_state(self.model)
+        opt_state = rdist.gather_sharded_optimizer_state(self.optimizer, self.model)   # (moments of the sharded rows too)
         if self.rank != 0:
             return
+        # `args.batch_size` is the per-rank batch; the file describes the GLOBAL batch (rows in rank order)
         common = {"epoch": epoch, "loss": loss, "kl_loss": self.kl_loss, "recon_loss": self.recon_loss,
                   "losses": self.losses, "bits_per_dim": self.bits, "annealing_counter": self.counter,
-                  "args": self.args, "args_dict": dict(vars(self.args))}
+                  "args": self.args, "args_dict": dict(vars(self.args)), "world_size": self.world,
+                  "global_batch_size": int(self.batch_size) * self.world}
         full = dict(common)
-        full.update({"model_state_dict": state, "optimizer_state_dict": self.optimizer.state_dict(),
+        full.update({"model_state_dict": state, "optimizer_state_dict": opt_state,
                      "plot_counter": self.plot_counter})
         torch.save(full, self.path + "model_folder/" + model_name)
         torch.save(common, self.path + "model_folder/eval_dict.pt")
+
+    @staticmethod
+    def args_for_world(ckpt, world):
+        """the Namespace to rebuild a Solver from `ckpt` on `world` ranks: the stored `batch_size` is per rank of the
+        run that wrote the file; the global batch is what is kept (files without `global_batch_size` -- the reference's
+        own -- are single-process: global = stored)."""
+        import copy
+        args = copy.copy(ckpt["args"])
+        gb = int(ckpt.get("global_batch_size", args.batch_size))
+        if gb % world:
+            raise ValueError("checkpoint global batch %d does not divide over %d ranks" % (gb, world))
+        args.batch_size = gb // world
+        for k in ("x_dim", "condition_dim"):   # [B, C, H, W] lists carry the batch too
+            v = getattr(args, k, None)
+            if isinstance(v, (list, tuple)) and len(v) == 4:
+                setattr(args, k, [gb // world] + list(v[1:]))
+        return args
 
     @staticmethod
     def read_checkpoint(path):
@@ -311,12 +332,9 @@ class Solver(object):
 
     def load(self, load_model):
         rdist.load_sharded_state(self.model, load_model["model_state_dict"])
-        try:
-            self.optimizer.load_state_dict(load_model["optimizer_state_dict"])
-        except ValueError:
-            if self.world == 1:
-                raise
-            # (the sharded initial states have other shapes per rank than in the file: their moments restart)
+        # the file holds the moments of the GLOBAL rows of the batch-sharded initial states: every rank takes its own
+        # (torch's load_state_dict does not compare shapes, and HipAdam indexes the moments by the parameter's numel)
+        self.optimizer.load_state_dict(rdist.shard_optimizer_state(load_model["optimizer_state_dict"], self.model))
         self.epoch_i += load_model["epoch"]
         loss = load_model["loss"]
         self.kl_loss, self.recon_loss = load_model["kl_loss"], load_model["recon_loss"]

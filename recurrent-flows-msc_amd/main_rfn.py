@@ -160,7 +160,8 @@ def main(args):
     if args.load_model:
         # rfn.pt may come from the reference (drop-in checkpoints): nothing from the file is executed
         ckpt = Solver.read_checkpoint("." + args.path + "model_folder/rfn.pt")
-        args = ckpt["args"]
+        # (a data-parallel checkpoint holds the global batch; this run may use another number of ranks)
+        args = Solver.args_for_world(ckpt, int(os.environ.get("WORLD_SIZE", 1)) if ckpt["args"].multigpu else 1)
         solver = Solver(args)
         solver.build()
         solver.load(ckpt)

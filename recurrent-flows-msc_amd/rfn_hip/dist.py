@@ -23,6 +23,14 @@ def is_dist():
     return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
 
+def collective_device(group=None):
+    """where a tensor must live to go through `group`'s backend: the current GPU for nccl (= RCCL, device memory only),
+    the host for gloo"""
+    if dist.get_backend(group) == "nccl":
+        return torch.device("cuda", torch.cuda.current_device())
+    return torch.device("cpu")
+
+
 class GradBucketReducer:
     """Flat-bucket asynchronous gradient averaging driven by post-accumulate-grad hooks."""
 
@@ -71,16 +79,33 @@ class GradBucketReducer:
         self._pending = [len(b) for b in self.buckets]
         self._works = []
 
+    def _flat_views(self, bi):
+        """the bucket's persistent flat buffer (allocated once, on the gradients' device) and one view per parameter"""
+        if self._flat[bi] is None:
+            b = self.buckets[bi]
+            flat = torch.empty(sum(p.numel() for p in b), device=b[0].device, dtype=b[0].dtype)
+            views, off = [], 0
+            for p in b:
+                views.append(flat[off:off + p.numel()].view_as(p))
+                off += p.numel()
+            self._flat[bi] = (flat, views)
+        return self._flat[bi]
+
     def _launch(self, bi):
+        """gather the bucket's gradients into its flat buffer (one multi-tensor copy, no allocation) and start ONE
+        in-place all-reduce on it"""
         b = self.buckets[bi]
-        grads = [p.grad if p.grad is not None else torch.zeros_like(p) for p in b]
-        flat = torch.cat([g.reshape(-1) for g in grads])
+        flat, views = self._flat_views(bi)
+        have = [(v, p.grad) for v, p in zip(views, b) if p.grad is not None]
+        if len(have) < len(b):
+            flat.zero_()   # parameters that got no gradient on this rank contribute zeros (others may have one)
+        if have:
+            torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
         if flat.is_cuda and dist.get_backend(self.group) == "gloo":
             # CPU-side collective on device memory (the one-GPU rehearsal of the N>1 path): without this the ranks sharing a
             # GPU were observed to stall for tens of seconds inside gloo's own stream hand-over
             torch.cuda.current_stream().synchronize()
         work = dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
-        self._flat[bi] = flat
         self._works.append((bi, work))
 
     def _on_grad(self, p):
@@ -102,21 +127,17 @@ class GradBucketReducer:
                 self._launch(bi)
         for bi, work in self._works:
             work.wait()
-            flat = self._flat[bi]
+            flat, views = self._flat[bi]
             flat.div_(self.world)
-            off, dst, src = 0, [], []
-            for p in self.buckets[bi]:
-                n = p.numel()
-                g = flat[off:off + n].view_as(p)
+            dst, src = [], []
+            for p, g in zip(self.buckets[bi], views):
                 if p.grad is None:
                     p.grad = g.clone()
                 else:
                     dst.append(p.grad)
                     src.append(g)
-                off += n
             if dst:
                 torch._foreach_copy_(dst, src)  # one multi-tensor launch per bucket instead of one copy per parameter
-            self._flat[bi] = None
         self.reset()
 
 
@@ -176,6 +197,71 @@ def all_reduce_mean_scalars(*vals, group=None):
     if not is_dist():
         return [float(v) for v in vals]
     t = torch.stack([v.detach().float().reshape(()) for v in vals])
+    t = t.to(collective_device(group))   # host scalars cannot go through an RCCL-only group
     dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     t /= dist.get_world_size(group)
     return [float(x) for x in t]
+
+
+def _sharded_param_indices(module, sharded_names=SHARDED_PARAM_NAMES):
+    """positions, in module.parameters() order (= the optimizer's parameter indices), of the batch-sharded states"""
+    return [i for i, (n, _) in enumerate(module.named_parameters()) if "." not in n and n in sharded_names]
+
+
+def gather_sharded_optimizer_state(optimizer, module, group=None, sharded_names=SHARDED_PARAM_NAMES):
+    """optimizer.state_dict() with the Adam moments of the batch-sharded initial states concatenated over ranks, like
+    `gather_sharded_state` does for the parameters themselves: the file then describes ONE process on the global batch
+    (rows in rank order).  Collective; every rank gets the dict."""
+    sd = optimizer.state_dict()
+    if not is_dist():
+        return sd
+    world = dist.get_world_size(group)
+    dev = collective_device(group)
+    state = dict(sd["state"])
+    for i in _sharded_param_indices(module, sharded_names):
+        st = state.get(i)
+        # every rank must enter the same collectives: a rank whose state has not been created yet contributes zeros
+        p = list(module.parameters())[i]
+        new = dict(st) if st is not None else {}
+        for k in ("exp_avg", "exp_avg_sq"):
+            v = (st[k] if st is not None and k in st else torch.zeros_like(p)).detach().to(dev).contiguous()
+            parts = [torch.empty_like(v) for _ in range(world)]
+            dist.all_gather(parts, v, group=group)
+            new[k] = torch.cat(parts, 0).to(p.device)
+        if st is not None:
+            state[i] = new
+    out = dict(sd)
+    out["state"] = state
+    return out
+
+
+def shard_optimizer_state(state_dict, module, group=None, sharded_names=SHARDED_PARAM_NAMES):
+    """the inverse on load: moments saved for the GLOBAL rows of a batch-sharded state are cut to this rank's rows.
+    Moments whose leading dimension fits neither the local nor the global batch are dropped (they restart from zero)
+    rather than handed to the kernel with a wrong size."""
+    world = dist.get_world_size(group) if is_dist() else 1
+    rank = dist.get_rank(group) if is_dist() else 0
+    params = list(module.parameters())
+    state = dict(state_dict["state"])
+    for i in _sharded_param_indices(module, sharded_names):
+        st = state.get(i)
+        if st is None:
+            continue
+        b = params[i].shape[0]
+        new = dict(st)
+        ok = True
+        for k in ("exp_avg", "exp_avg_sq"):
+            v = st.get(k)
+            if v is None:
+                continue
+            if v.shape[0] == b * world and tuple(v.shape[1:]) == tuple(params[i].shape[1:]):
+                new[k] = v[rank * b:(rank + 1) * b].clone()
+            elif tuple(v.shape) != tuple(params[i].shape):
+                ok = False
+        if ok:
+            state[i] = new
+        else:
+            del state[i]
+    out = dict(state_dict)
+    out["state"] = state
+    return out

@@ -62,6 +62,10 @@ class HipAdam(torch.optim.Adam):
                     raise RuntimeError("HipAdam: %s must be a dense fp32 device tensor (got %s %s, contiguous=%s)" %
                                        (name, t.dtype, t.device, t.is_contiguous()))
             n = p.numel()
+            for name, t in (("gradient", g), ("exp_avg", m), ("exp_avg_sq", v)):
+                if t.numel() != n:   # e.g. moments of another batch size loaded from a checkpoint: the kernel indexes by n
+                    raise RuntimeError("HipAdam: %s has %d elements, its parameter %d (shape %s)" %
+                                       (name, t.numel(), n, tuple(p.shape)))
             off = self._t - self._steps[id(p)]
             ent[i] = (p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), n, off & 0xFFFFFFFF)
             nck = (n + chunk - 1) // chunk
@@ -104,4 +108,7 @@ class HipAdam(torch.optim.Adam):
                ctypes.c_double(float(group["lr"])), ctypes.c_double(beta1), ctypes.c_double(beta2),
                ctypes.c_double(group["eps"]), ctypes.c_double(group["weight_decay"]), ctypes.c_int(self._t),
                meta=("shell", "adam", 0.0, "%d tensors" % len(plist), nbytes))
+        # the kernel wrote through raw pointers: tell autograd's version counters, which everything keyed on
+        # `p._version` relies on (ListGlow._reverse_cache, RFN._gen_graph: cached inverse matrices / packs / hipGraph)
+        torch.autograd.graph.increment_version(plist)
         return loss

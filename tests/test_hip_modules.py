@@ -771,6 +771,58 @@ def test_graphed_generation_equals_eager_generation(conv_precision, monkeypatch)
                 prm.add_(0.01 * torch.randn_like(prm))
 
 
+def test_generation_follows_hipadam_updates(tmp_path, conv_precision, monkeypatch):
+    """HipAdam updates parameters through a raw-pointer kernel launch; the generation caches
+    (ListGlow._reverse_cache: inverse 1x1 matrices and weight packs; RFN._gen_graph: the captured per-frame hipGraph) are
+    keyed on the parameters' version counters, so the optimizer must bump them.  predict -> train steps with HipAdam (the
+    Solver's GPU optimizer) -> predict again: the cached / graphed frames must equal an uncached eager generation on the
+    new weights, and must differ from the frames of the old weights."""
+    if conv_precision != "mixed":
+        pytest.skip("cache logic: run once")
+    import rfn_hip
+    import os as _os
+    from RFN.trainer import Solver
+    from RFN import RFN
+    from rfn_hip import dist as rdist
+    from rfn_hip.optim import HipAdam
+    rel = "/" + _os.path.relpath(str(tmp_path), _os.getcwd()) + "/"
+    args = _tiny_solver_args(rel)
+    torch.manual_seed(31)
+    s = Solver(args)
+    s.device = torch.device("cuda")
+    s.model = RFN(args).cuda().train()
+    s.reducer = rdist.GradBucketReducer(list(s.model.named_parameters()))
+    s.optimizer = Solver.make_optimizer(s.model.parameters(), 2e-2)   # large steps: the frames must visibly move
+    assert isinstance(s.optimizer, HipAdam)
+    g = torch.Generator().manual_seed(32)
+    xs = [torch.rand(2, 4, 1, 16, 16, generator=g).cuda() for _ in range(2)]
+    x = s.preprocess(xs[0])
+    s.train_step(xs[0])                # data dependent init + first update
+    graph_ok = rfn_hip.graph_capture_safe()
+
+    def gen(cached):
+        monkeypatch.setenv("RFN_GEN_GRAPH", "1" if (cached and graph_ok) else "0")
+        monkeypatch.setenv("RFN_GEN_CACHE", "1" if cached else "0")
+        s.model.eval()
+        torch.manual_seed(41)
+        _, pred = s.model.predict(x, 2, 2)
+        torch.manual_seed(42)
+        smp = s.model.sample(x, 2)
+        s.model.train()
+        return pred.cuda().clone(), smp.cuda().clone()
+
+    p0, s0 = gen(True)                 # fills the caches (and captures the generation graph) on the current weights
+    v0 = [p._version for p in s.model.parameters()]
+    for i in range(3):
+        s.train_step(xs[i % 2])        # HipAdam: raw-pointer updates
+    assert all(p._version > v for p, v in zip(s.model.parameters(), v0) if p.grad is not None)
+    p1, s1 = gen(True)                 # must NOT reuse the stale inverse matrices / packs / graph
+    pe, se = gen(False)                # uncached eager generation on the new weights
+    close(p1, pe.cpu(), 1e-4, 1e-5)
+    close(s1, se.cpu(), 1e-4, 1e-5)
+    assert float((p1 - p0).abs().max()) > 1e-3 and float((s1 - s0).abs().max()) > 1e-3
+
+
 def test_training_trajectory_split_precision_vs_fp32_mfma(tmp_path, conv_precision):
     """20 Adam steps on the tiny configuration: the loss trajectory of the shipped arithmetic ('mixed', and 'bf16x3') stays
     on the trajectory of the all-fp32-MFMA kernels -- same initial weights, same batches, same noise (the RNG is re-seeded

@@ -3,6 +3,7 @@ the argument lists the ctypes binding assumes), the drop-in modules build with t
 trainer arithmetic, CLI flags, the synthetic data contract, loud failure without a GPU, and the data-parallel
 gradient reducer over a 2-rank gloo group."""
 import os
+import json
 import re
 import subprocess
 import sys
@@ -184,6 +185,29 @@ with torch.no_grad():
     m.h_0.zero_()
 rdist.load_sharded_state(m, full)
 assert torch.equal(m.h_0.detach(), H[rank * B_local:(rank + 1) * B_local])
+# the Adam moments of the sharded rows travel the same way (ADVICE r2: a checkpoint must describe ONE process on the
+# global batch, and a loaded moment must have its parameter's size): gather -> global rows, shard -> my rows back
+opt = torch.optim.Adam(m.parameters(), lr=1e-2)
+opt.step()
+osd = rdist.gather_sharded_optimizer_state(opt, m)
+names = [n for n, _ in m.named_parameters()]
+i_h = names.index("h_0")
+assert tuple(osd["state"][i_h]["exp_avg"].shape) == (world * B_local, 3)
+parts = [torch.empty_like(opt.state[m.h_0]["exp_avg"]) for _ in range(world)]
+dist.all_gather(parts, opt.state[m.h_0]["exp_avg"])
+assert torch.equal(osd["state"][i_h]["exp_avg"], torch.cat(parts, 0))
+assert torch.equal(osd["state"][names.index("big")]["exp_avg"], opt.state[m.big]["exp_avg"])   # replicated: untouched
+back = rdist.shard_optimizer_state(osd, m)
+assert torch.equal(back["state"][i_h]["exp_avg"], opt.state[m.h_0]["exp_avg"])
+assert torch.equal(back["state"][i_h]["exp_avg_sq"], opt.state[m.h_0]["exp_avg_sq"])
+opt2 = torch.optim.Adam(m.parameters(), lr=1e-2)
+opt2.load_state_dict(back)
+assert opt2.state[m.h_0]["exp_avg"].shape == m.h_0.shape
+# moments that fit neither the local nor the global batch are dropped, not handed on with a wrong size
+bad = {"state": {i_h: {"step": torch.tensor(1.0), "exp_avg": torch.zeros(7, 3), "exp_avg_sq": torch.zeros(7, 3)}},
+       "param_groups": osd["param_groups"]}
+assert i_h not in rdist.shard_optimizer_state(bad, m)["state"]
+assert rdist.collective_device().type == "cpu"   # gloo group: host tensors
 dist.destroy_process_group()
 print("rank %d ok" % rank)
 """
@@ -329,14 +353,60 @@ def test_bench_roofline_groups_by_kernel_symbol():
     for _ in range(2):  # two "steps"
         records += [rec("rfn_conv2d_fwd_bf16x3", "conv", "kernA", 1e12, 2e9, 1.0),
                     rec("rfn_conv2d_dgrad_act_bf16x3", "conv", "kernA+actbwd", 1e12, 4e9, 1.5),
-                    rec("rfn_gemm_wgrad_bf16x3", "wgrad", "kernB", 3e12, 1e9, 2.0),
+                    rec("rfn_gemm_wgrad_bf16x3", "wgrad", "kernB<1,2>", 1.5e12, 0.5e9, 1.0),
+                    rec("rfn_gemm_wgrad_bf16x3", "wgrad", "kernB<grouped 3,4>", 1.5e12, 0.5e9, 1.0),
+                    rec("rfn_conv2d_fwd_bf16x6", "conv", "kernB<1,2> x6", 1e12, 1e9, 0.3),   # other arithmetic: apart
                     ("rfn_squeeze2d_f32", None, Ev(0.0), Ev(0.25))]
     roof, table = bench.kernel_roofline(records, 2)
-    assert roof["kernel"] == "kernA" and roof["launches_per_step"] == 2       # 2.5 ms/step beats kernB's 2.0
+    # instantiations of one template are ONE kernel: kernB = 2.0 ms/step, kernA (with its +actbwd mode) 2.5
+    assert roof["kernel"] == "kernA" and roof["launches_per_step"] == 2
     assert abs(roof["avg_launch_us"] - 1250.0) < 1e-6
     assert abs(roof["hbm"]["achieved_GBps"] - 6e9 / 2.5e-3 / 1e9) < 1e-6      # (2e9 + 4e9) B in 2.5 ms
     assert abs(roof["mfma"]["achieved_TFLOPs_fp32_equiv"] - 2e12 / 2.5e-3 / 1e12) < 1e-6
     assert roof["bound"] in ("hbm", "mfma") and 0 < roof["frac"] <= 1.5
-    assert abs(roof["hip_kernel_ms_per_step"] - 4.75) < 1e-9
+    assert abs(roof["hip_kernel_ms_per_step"] - 5.05) < 1e-9
     names = [r[0] for r in table["kernels"]]
-    assert "kernA" in names and "kernA+actbwd" in names and "rfn_squeeze2d_f32" in names
+    assert "kernA" in names and "kernA+actbwd" in names and "rfn_squeeze2d_f32" in names and "kernB<1,2>" in names
+    # with the template's instantiations summed it can become the dominant kernel
+    records += [rec("rfn_gemm_wgrad_bf16x3", "wgrad", "kernB<9>", 1e12, 1e9, 1.2) for _ in range(2)]
+    roof2, _ = bench.kernel_roofline(records, 2)
+    assert roof2["kernel"] == "kernB" and roof2["launches_per_step"] == 3
+
+
+_RANK_STUB = """
+import json, os, sys, time
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(rank) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+mode = sys.argv[1]
+if mode == "ok":
+    if rank == 0:
+        print("noise line")
+        print(json.dumps({"n_gpus": world, "argv": sys.argv[2:], "port": os.environ["MASTER_PORT"]}))
+    sys.exit(0)
+if mode == "fail1":          # rank 1 dies; the others would wait for a rendezvous for ever
+    if rank == 1:
+        sys.exit(7)
+    time.sleep(120)
+"""
+
+
+def test_bench_self_launches_its_ranks(tmp_path, capsys):
+    """`python bench.py --gpus N` without a launcher: the GPU-less parent starts N ranks with the torchrun environment,
+    passes rank 0's JSON line through, and turns a failing rank into a non-zero exit code without hanging (VERDICT r2
+    item 2; the rank body is a stub here -- the real one needs GPUs)."""
+    import time
+    sys.path.insert(0, ROOT)
+    import bench
+    stub = tmp_path / "rank_stub.py"
+    stub.write_text(_RANK_STUB)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    rc = bench.launch_ranks(3, ["ok", "--gpus", "3"], env=env, script=str(stub))
+    out = [l for l in capsys.readouterr().out.splitlines() if l.startswith("{")]
+    assert rc == 0 and len(out) == 1
+    rec = json.loads(out[0])
+    assert rec["n_gpus"] == 3 and rec["argv"] == ["--gpus", "3"]
+    t0 = time.time()
+    rc = bench.launch_ranks(2, ["fail1"], env=env, script=str(stub))
+    assert rc == 7 and time.time() - t0 < 60
+    assert bench._gpus_arg(["--steps", "3", "--gpus", "4"]) == 4 and bench._gpus_arg(["--gpus=2"]) == 2
+    assert bench._gpus_arg(["--steps", "3"]) == 1
