@@ -146,7 +146,19 @@ int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_st
  *   rfn_coupling_po_fwd  z: output of ActNorm+InvConv [N, >=C/2, H, W] (channels [0, C/2) are read), cond [N, Cc, H, W];
  *       n1b/n1l, n2b/n2l: ActNorm bias / logs [256] of the hidden layers; act 0 none, 1 relu, 2 leaky .2.
  *       Outputs h1, h2 [N, 256, H, W] and P [N, 9C, H, W], P[tap*C + co] = sum_c w3[co][c][tap] h2[c]
- *       (rfn_tap_gather_f32 turns P into the Conv2dZeros output). */
+ *       (rfn_tap_gather_f32 turns P into the Conv2dZeros output); m1 / m2 (nullable, rfn_coupling_po_mask_floats(N, H, W)
+ *       floats each, 16-byte aligned): 1-bit masks "h <= 0" of h1 / h2 in the backward kernel's (round, thread,
+ *       register) order -- act'(.) for rfn_coupling_po_bwd, 1/32 of the activations' bytes.
+ * Backward of the same three convolutions' DATA path (backward of glow_modules.py:232-238), one kernel:
+ *   rfn_coupling_po_bwd_supported / rfn_coupling_po_bwd_packed_bytes / rfn_coupling_po_pack_bwd  as above for the
+ *       backward stream (w3 transposed + mirrored, w2 transposed; descs: w2, w3, dst, C are read);
+ *   rfn_coupling_po_bwd  go [N, C, H, W] = gradient at conv3's output ->
+ *       ga2 = (conv3^T go) act'(h2) exp(n2l), ga1 = (w2^T ga2) act'(h1) exp(n1l)  [N, 256, H, W] each (the gradients at
+ *       the outputs of conv2 / conv1: operands of the weight gradients and of conv1's data gradient), and
+ *       part (rfn_coupling_po_bwd_part_floats(N, H, W) floats, written): per-workgroup sums over pixels of ga2 | ga1;
+ *   rfn_coupling_po_bwd_finish  for n <= 16 nets (host arrays of n device pointers): ActNorm gradients
+ *       out[i] = [gn1b | gn1l | gn2b | gn2l] (4 x 256) with gnb = sum of the part rows (nblk of them) and
+ *       gnl[c] = sum_k w[c][k] gw[c][k] + nb[c] gnb[c]  (K1 = Cin * 9 elements per row of w1 / gw1, 256 of w2 / gw2). */
 typedef struct {
     const float* w1;  /* [256][C/2 + Cc][3][3] */
     const float* w2;  /* [256][256][1][1] */
@@ -159,8 +171,20 @@ long rfn_coupling_po_packed_bytes(int Cin, int C);
 int rfn_coupling_po_pack(const void* descs_device, int n, rfn_stream_t stream);
 int rfn_coupling_po_fwd(const float* z, long z_ns, const float* cond, long cond_ns, const void* wpk, const float* n1b,
                         const float* n1l, const float* n2b, const float* n2l, float* h1, long h1_ns, float* h2,
-                        long h2_ns, float* P, long P_ns, int N, int C, int Cc, int H, int W, int act,
+                        long h2_ns, float* P, long P_ns, float* m1, float* m2, int N, int C, int Cc, int H, int W, int act,
                         rfn_stream_t stream);
+long rfn_coupling_po_mask_floats(int N, int H, int W);
+int rfn_coupling_po_bwd_supported(int N, int C, int H, int W);
+long rfn_coupling_po_bwd_packed_bytes(int C);
+int rfn_coupling_po_pack_bwd(const void* descs_device, int n, rfn_stream_t stream);
+long rfn_coupling_po_bwd_part_floats(int N, int H, int W);
+int rfn_coupling_po_bwd(const float* go, long go_ns, const void* wpk, const float* n1l, const float* n2l,
+                        const float* m_h1, const float* m_h2, float* ga2, long ga2_ns, float* ga1, long ga1_ns,
+                        float* part, int N, int C, int H, int W, int act, rfn_stream_t stream);
+int rfn_coupling_po_bwd_finish(const float* const* part, const float* const* w1, const float* const* gw1,
+                               const float* const* n1b, const float* const* w2, const float* const* gw2,
+                               const float* const* n2b, float* const* out, int n, int nblk, int K1,
+                               rfn_stream_t stream);
 
 /* ---- a5/a6 fused shell tail of GlowStep.forward (Flow/glow_modules.py:119-121 + :276-285): with P (tap-expanded
  * Conv2dZeros output, [N,9C,H,W]) the 3x3 shift-and-add, bias and exp(3 logs) scale are applied here and the result is

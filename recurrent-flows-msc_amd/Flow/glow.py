@@ -186,7 +186,8 @@ class ListGlow(nn.Module):
         """two launches re-pack every coupling-net weight of the flow: the split-precision (bf16x3) packs of the
         data-gradient convolutions -- and of the forward convolutions where bf16x3 is the forward arithmetic -- and the
         fragment streams of the fused forward kernel (shallow levels, 'mixed' arithmetic).
-        Returns {GlowStep: (w1 f, w1 d, w2 f, w2 d, w3 f, w3 d, fused stream)} (entries None where unused) or None."""
+        Returns {GlowStep: (w1 f, w1 d, w2 f, w2 d, w3 f, w3 d, fused forward stream, fused backward stream)} (entries
+        None where unused) or None."""
         if not K.bwd_b3():
             return None
         levels = self._level_steps()
@@ -226,8 +227,9 @@ class ListGlow(nn.Module):
             po = getattr(self, "_po_plan", None)
             if po is None or not po.valid_for(nets):
                 po = self._po_plan = K.POPackPlan(nets)
-            po.run()
-        return {s: tuple((None if i is None else plan.bufs[i]) for i in sl[:6]) + ((None if sl[6] is None else po.bufs[sl[6]]),)
+            po.run(bwd=torch.is_grad_enabled())
+        return {s: tuple((None if i is None else plan.bufs[i]) for i in sl[:6])
+                + ((None if sl[6] is None else po.bufs[sl[6]]), (None if sl[6] is None else po.bwd_bufs[sl[6]]))
                 for s, sl in slots.items()}
 
     def f(self, x, condition, logdet):

@@ -45,7 +45,6 @@ typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 #define PO_TAP_PAIRS 5     // 9 taps in pairs (the lane half selects the tap of a pair); the 10th tap is zero weight
 #define PO_WAVES 4
 #define PO_ROUND_PX (32 * PO_WAVES)
-#define PO_ITEMS 4         // staging items per thread (NG * IPOS <= 1024)
 
 // ---- geometry of the forward weight stream (host + device).  Unit: fragment = 64 lanes x 16 B = 1 KB; two planes
 // (hi, lo) per logical fragment.  Fragment 0 is a header: floats {1/s_w1, 1/s_w2, 1/s_w3}.  Then, consumed in order:
@@ -60,10 +59,11 @@ struct POGeom {
     int c3;            // first fragment of the conv3 part
     int total_frags;
 };
-__host__ __device__ static inline POGeom po_geom(int Cin, int C) {
+// bwd: the stream of the backward kernel (data-gradient chain): no conv3 part
+__host__ __device__ static inline POGeom po_geom(int Cin, int C, bool bwd = false) {
     POGeom g;
     g.NG = (Cin + 7) / 8;
-    g.NP = (9 * C + 31) / 32;
+    g.NP = bwd ? 0 : (9 * C + 31) / 32;
     g.NS1 = PO_TAP_PAIRS * g.NG;
     g.quad_frags = g.NG * 40 + 4 * 32;
     g.c3 = 1 + 2 * g.quad_frags;
@@ -123,12 +123,16 @@ __device__ __forceinline__ void po_split_f16(const float (&v)[8], const float sc
 }
 
 // grid (3, n): block (c, d) = max |w| of convolution c of descriptor d -> header {1/s_w1, 1/s_w2, 1/s_w3}
+// BWD (stream of the backward kernel, see coupling_po_bwd below): "conv1" = w3 transposed and mirrored, "conv2" = w2
+// transposed; header {1/s_w3, 1/s_w2, 1}
+template <bool BWD>
 __global__ __launch_bounds__(256) void po_pack_scale_kernel(const POPackDesc* __restrict__ descs) {
     __shared__ float sm[4];
     const POPackDesc d = descs[blockIdx.y];
     const int c = blockIdx.x;
-    const float* w = c == 0 ? d.w1 : (c == 1 ? d.w2 : d.w3);
-    const long n = c == 0 ? (long)PO_HD * d.Cin * 9 : (c == 1 ? (long)PO_HD * PO_HD : (long)d.C * PO_HD * 9);
+    const float* w = BWD ? (c == 0 ? d.w3 : d.w2) : (c == 0 ? d.w1 : (c == 1 ? d.w2 : d.w3));
+    long n = c == 0 ? (long)PO_HD * d.Cin * 9 : (c == 1 ? (long)PO_HD * PO_HD : (long)d.C * PO_HD * 9);
+    if (BWD) n = c == 0 ? (long)d.C * PO_HD * 9 : (c == 1 ? (long)PO_HD * PO_HD : 0);
     float m = 0.f;
     for (long i = threadIdx.x; i < n; i += 256) m = fmaxf(m, fabsf(w[i]));
 #pragma unroll
@@ -143,9 +147,13 @@ __global__ __launch_bounds__(256) void po_pack_scale_kernel(const POPackDesc* __
     }
 }
 
+template <bool BWD>
 __global__ __launch_bounds__(256) void po_pack_fwd_kernel(const POPackDesc* __restrict__ descs) {
     const POPackDesc d = descs[blockIdx.y];
-    const POGeom g = po_geom(d.Cin, d.C);
+    // BWD: the first product is the data gradient of conv3 written as a 3x3 convolution of the C-channel gradient
+    // image: w1'[c2][co][tap] = w3[co][c2][8 - tap] ("Cin" = C); the second is w2'[c1][c2] = w2[c2][c1]; no third
+    const int Cin = BWD ? d.C : d.Cin;
+    const POGeom g = po_geom(Cin, d.C, BWD);
     f16x8* dst = reinterpret_cast<f16x8*>(d.dst);
     float scw[3];
 #pragma unroll
@@ -171,7 +179,9 @@ __global__ __launch_bounds__(256) void po_pack_fwd_kernel(const POPackDesc* __re
 #pragma unroll
                 for (int j = 0; j < 8; ++j) {
                     const int ci = 8 * gg + j;
-                    if (ci < d.Cin) v[j] = d.w1[((long)(32 * a + r) * d.Cin + ci) * 9 + tap];
+                    if (ci < Cin)
+                        v[j] = BWD ? d.w3[((long)ci * PO_HD + (32 * a + r)) * 9 + (8 - tap)]
+                                   : d.w1[((long)(32 * a + r) * Cin + ci) * 9 + tap];
                 }
             }
         } else if (k < n1 + n2) {
@@ -182,7 +192,7 @@ __global__ __launch_bounds__(256) void po_pack_fwd_kernel(const POPackDesc* __re
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int c1 = 16 * s + 8 * (j >> 2) + 4 * kk + (j & 3);
-                v[j] = d.w2[(long)(32 * a2 + r) * PO_HD + c1];
+                v[j] = BWD ? d.w2[(long)c1 * PO_HD + (32 * a2 + r)] : d.w2[(long)(32 * a2 + r) * PO_HD + c1];
             }
         } else {
             k -= n1 + n2;
@@ -207,13 +217,27 @@ __global__ __launch_bounds__(256) void po_pack_fwd_kernel(const POPackDesc* __re
 }
 
 extern "C" long rfn_coupling_po_packed_bytes(int Cin, int C) { return (long)po_geom(Cin, C).total_frags * 1024; }
+extern "C" long rfn_coupling_po_bwd_packed_bytes(int C) { return (long)po_geom(C, C, true).total_frags * 1024; }
 
 extern "C" int rfn_coupling_po_pack(const void* descs_device, int n, rfn_stream_t stream) {
     RFN_CHECK_ARG(descs_device && n >= 0, -1);
     if (n == 0) return 0;
-    hipLaunchKernelGGL(po_pack_scale_kernel, dim3(3, n), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(po_pack_scale_kernel<false>, dim3(3, n), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const POPackDesc*>(descs_device));
-    hipLaunchKernelGGL(po_pack_fwd_kernel, dim3(16, n), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(po_pack_fwd_kernel<false>, dim3(16, n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const POPackDesc*>(descs_device));
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+/* the backward kernel's stream of n coupling nets (descs: w2, w3, dst = rfn_coupling_po_bwd_packed_bytes(C) bytes, C;
+ * w1 / Cin are not read) */
+extern "C" int rfn_coupling_po_pack_bwd(const void* descs_device, int n, rfn_stream_t stream) {
+    RFN_CHECK_ARG(descs_device && n >= 0, -1);
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(po_pack_scale_kernel<true>, dim3(3, n), dim3(256), 0, (hipStream_t)stream,
+                       reinterpret_cast<const POPackDesc*>(descs_device));
+    hipLaunchKernelGGL(po_pack_fwd_kernel<true>, dim3(16, n), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const POPackDesc*>(descs_device));
     RFN_LAUNCH_CHECK();
     return 0;
@@ -231,6 +255,12 @@ struct POFwdParams {
     int rpf_shift;   // log2(rounds per frame), a round = 128 consecutive pixels of one frame
     int n_rounds;    // N * H * W / 128
     int IW, IPOS;    // haloed image of a round: (128/W + 2) rows x (W + 2) columns
+    // activation masks, one uint4 per (round, thread): bit 16 (a & 1) + r of word a >> 1 is set when register r of the
+    // thread's tile a (channels 32 a + 4 kk + 8 (r >> 2) + (r & 3) of its pixel) is NOT in the activation's linear
+    // region (value <= 0).  Forward: written (m1 for h1, m2 for h2; nullptr = not wanted).  Backward: read (m1 masks the
+    // first stage = h2's mask, m2 the second = h1's).
+    unsigned* m1; unsigned* m2;
+    float* part;     // backward: [gridDim.x][2][256] per-workgroup sums over pixels of the two stages' outputs
 };
 
 #define PO_MFMA(acc, a, b) acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, acc, 0, 0, 0)
@@ -242,9 +272,10 @@ __device__ __forceinline__ void po_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)
 // values of this lane (channels 4kk + 8q + i of the tile at this lane's pixel), running max of |v|.
 // pb -> bias of the tile's first channel of this lane half (exp(logs) 256 floats further);
 // rsrc / voff: buffer descriptor of the output tensor and this lane's byte offset of (frame, first channel, pixel).
-template <int ACT>
+// mask: bit SH + r is set when value r is outside the activation's linear region (the backward kernel's act'(y))
+template <int ACT, int SH>
 __device__ __forceinline__ void po_epilogue(f32x16& acc, const float u, const float* pb, const __amdgpu_buffer_rsrc_t rsrc,
-                                            const unsigned voff, const unsigned ch_bytes, float& vmax) {
+                                            const unsigned voff, const unsigned ch_bytes, float& vmax, unsigned& mask) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 b4 = *reinterpret_cast<const f32x4*>(pb + 8 * q);
@@ -254,10 +285,47 @@ __device__ __forceinline__ void po_epilogue(f32x16& acc, const float u, const fl
             float t = fmaf(acc[4 * q + i], u, b4[i]) * e4[i];
             if (ACT == 1) t = fmaxf(t, 0.f);
             if (ACT == 2) t = fmaxf(t, 0.2f * t);
+            if (ACT != 0) mask |= t > 0.f ? 0u : (1u << (SH + 4 * q + i));
             acc[4 * q + i] = t;
             vmax = fmaxf(vmax, fabsf(t));
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rsrc, voff, (8 * q + i) * ch_bytes, 0);
         }
+    }
+}
+
+// Backward counterpart: acc holds the gradient wrt the layer's activated output h = act((a + b) exp(l)); the tile
+// becomes ga = acc * u * act'(.) * exp(l) = the gradient wrt the convolution output a (what the weight gradient and the
+// next data gradient consume), is stored, and its sum over the wave's pixels is added to the workgroup's per-channel sums
+// in LDS (gs -> slot [channel of register 0][quad of this lane]; 8 slots per channel): two DPP adds bring the four
+// pixels of a lane quad together, one lane per quad issues the LDS atomic.  (Sum over pixels of ga = gradient of the
+// ActNorm bias; the gradient of its logs follows from the weight gradient, see po_bwd_finish_kernel.)
+template <int ACT>
+__device__ __forceinline__ void po_epilogue_bwd(f32x16& acc, const float u, const float* pe,
+                                                const __amdgpu_buffer_rsrc_t rsrc, const unsigned voff,
+                                                const unsigned ch_bytes, float& vmax, const unsigned mbits, float* gs,
+                                                const bool quad_leader) {
+    float sum[16];
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        const f32x4 e4 = *reinterpret_cast<const f32x4*>(pe + 8 * q);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            float t = acc[4 * q + i] * u * e4[i];
+            const bool off = (mbits >> (4 * q + i)) & 1u;
+            if (ACT == 1) t = off ? 0.f : t;
+            if (ACT == 2) t = off ? 0.2f * t : t;
+            acc[4 * q + i] = t;
+            vmax = fmaxf(vmax, fabsf(t));
+            __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rsrc, voff, (8 * q + i) * ch_bytes, 0);
+            float v = t;
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
+            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
+            sum[4 * q + i] = v;
+        }
+    }
+    if (quad_leader) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) atomicAdd(gs + (8 * (r >> 2) + (r & 3)) * 8, sum[r]);
     }
 }
 
@@ -268,19 +336,31 @@ __device__ __forceinline__ int po_exp_of(const float m) {
     return E > 250 ? 250 : E;
 }
 
-template <int NG, int NP, int LOGW, int ACT>
+// BWD = the data-gradient chain of the same network on the same machinery (backward of glow_modules.py:232-238 from
+// the gradient `go` at conv3's output; NP = 0):
+//     gh2 = conv3^T go          a 3x3 convolution of the C-channel image go with w3 transposed + mirrored  ("conv1")
+//     ga2 = gh2 act'(h2) exp(l2)    stored: the weight gradient of conv2 and of conv3's ... consume it    (epilogue)
+//     gh1 = w2^T ga2            K-major on the register-resident ga2                                       ("conv2")
+//     ga1 = gh1 act'(h1) exp(l1)    stored: weight gradient and data gradient of conv1 consume it          (epilogue)
+// act'(.) comes from the 1-bit masks the forward kernel wrote in this kernel's own (round, thread, register) order, so
+// the 637 MB activations are not read here at all; per-channel sums of ga2 / ga1 (ActNorm bias gradients) leave as
+// per-workgroup partial rows.  Parameter roles in BWD: z = go (Ch = C, Cc = 0), n1l = l2, n2l = l1, h1 = ga2, h2 = ga1,
+// m1 = mask of h2, m2 = mask of h1.
+template <int NG, int NP, int LOGW, int ACT, bool BWD>
 __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const POFwdParams p) {
     // square maps of side W = 2^LOGW: a round is 128 / W image rows; its haloed image has IW columns, IPOS positions
     constexpr int W = 1 << LOGW, HW = W * W, IW = W + 2, IPOS = (PO_ROUND_PX / W + 2) * IW;
+    constexpr int PO_ITEMS = (NG * IPOS + 64 * PO_WAVES - 1) / (64 * PO_WAVES);   // staging items per thread
     constexpr int RPF_SHIFT = 2 * LOGW - 7;   // log2(rounds per frame)
     constexpr int G3 = 8 * NP;                 // fragments per conv3 group
     constexpr int SLOTF = 40 > G3 ? 40 : G3;
     constexpr int SLOT = SLOTF * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int NGRP = 2 * NG + 12;                                      // weight groups per round
+    constexpr int NGRP = 2 * NG + 8 + (BWD ? 0 : 4);                       // weight groups per round
     float* par = reinterpret_cast<float*>(lds + 3 * SLOT);                 // [4][256]: b1, exp(l1), b2, exp(l2)
     float* red = par + 1024;                                               // [8] block reductions
     f16x8* img = reinterpret_cast<f16x8*>(lds + 3 * SLOT + 4096 + 64);      // [plane 2][NG][IPOS]
+    float* gsum = reinterpret_cast<float*>(lds + 3 * SLOT + 4096 + 64 + 2 * NG * IPOS * 16);   // BWD: [2][256][8]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
@@ -288,11 +368,13 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
     constexpr unsigned ch_bytes = (unsigned)HW * 4u;
 
     for (int c = tid; c < 256; c += 64 * PO_WAVES) {
-        par[c] = p.n1b[c];
+        par[c] = BWD ? 0.f : p.n1b[c];
         par[256 + c] = expf(p.n1l[c]);
-        par[512 + c] = p.n2b[c];
+        par[512 + c] = BWD ? 0.f : p.n2b[c];
         par[768 + c] = expf(p.n2l[c]);
     }
+    if (BWD)
+        for (int c = tid; c < 2 * 256 * 8; c += 64 * PO_WAVES) gsum[c] = 0.f;
     const float* hdr = reinterpret_cast<const float*>(p.wpk);
     const float inv_w1 = hdr[0], inv_w2 = hdr[1], inv_w3 = hdr[2];
     __syncthreads();
@@ -425,6 +507,17 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         const float* par1 = par + 4 * kk;
         const float* par2 = par + 512 + 4 * kk;
 
+        // activation masks of this thread's (round, registers): written forward, read backward
+        unsigned mk1[4] = {0u, 0u, 0u, 0u}, mk2[4] = {0u, 0u, 0u, 0u};   // (forward: dead, see the epilogues)
+        if (BWD && ACT != 0) {
+            const uint4 a_ = reinterpret_cast<const uint4*>(p.m1)[(long)round * (64 * PO_WAVES) + tid];
+            const uint4 b_ = reinterpret_cast<const uint4*>(p.m2)[(long)round * (64 * PO_WAVES) + tid];
+            mk1[0] = a_.x; mk1[1] = a_.y; mk1[2] = a_.z; mk1[3] = a_.w;
+            mk2[0] = b_.x; mk2[1] = b_.y; mk2[2] = b_.z; mk2[3] = b_.w;
+        }
+        const bool quad_leader = (lane & 3) == 0;
+        float* gs1 = gsum + (4 * kk) * 8 + (l31 >> 2);   // + 32 a * 8 per tile; second stage 2048 floats further
+
         f32x16 acc2[8];   // conv2 accumulators = h2 (all 256 channels of this lane's pixel half)
 #pragma unroll
         for (int a2 = 0; a2 < 8; ++a2)
@@ -487,10 +580,22 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
             }
             // ---- epilogue of the four tiles: ActNorm + act, store h1, per-pixel maximum
             float vmax = 0.f;
+            unsigned mq[2] = {0u, 0u};   // forward: the quad's two mask words (words 2u, 2u+1 of the thread's uint4), stored at once
 #pragma unroll
-            for (int t = 0; t < 4; ++t)
-                po_epilogue<ACT>(Q[t], u1, par1 + 32 * (4 * u + t), rs_h1, vo1 + (unsigned)(32 * (4 * u + t)) * ch_bytes,
-                                 ch_bytes, vmax);
+            for (int t = 0; t < 4; ++t) {
+                const int a = 4 * u + t;   // tile: mask word a >> 1, bits 16 (a & 1) ..
+                if (BWD)
+                    po_epilogue_bwd<ACT>(Q[t], u1, par1 + 256 + 32 * a, rs_h1, vo1 + (unsigned)(32 * a) * ch_bytes, ch_bytes,
+                                         vmax, mk1[a >> 1] >> (16 * (a & 1)), gs1 + 32 * a * 8, quad_leader);
+                else if (t & 1)
+                    po_epilogue<ACT, 16>(Q[t], u1, par1 + 32 * a, rs_h1, vo1 + (unsigned)(32 * a) * ch_bytes, ch_bytes,
+                                         vmax, mq[t >> 1]);
+                else
+                    po_epilogue<ACT, 0>(Q[t], u1, par1 + 32 * a, rs_h1, vo1 + (unsigned)(32 * a) * ch_bytes, ch_bytes,
+                                        vmax, mq[t >> 1]);
+            }
+            if (!BWD && ACT != 0 && p.m1)
+                reinterpret_cast<uint2*>(p.m1)[((long)round * (64 * PO_WAVES) + tid) * 2 + u] = make_uint2(mq[0], mq[1]);
             vmax = fmaxf(vmax, __shfl_xor(vmax, 32, 64));   // the other lane half holds the pixel's other channels
             const int Enew = max(Erun, po_exp_of(vmax));
             if (u > 0 && __any(Enew != Erun)) {
@@ -524,7 +629,9 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
                 if (g2 < 2) PO_BOUNDARY(u * (NG + 4) + NG + g2, 8 + 64);
                 else if (g2 == 2) PO_BOUNDARY(u * (NG + 4) + NG + g2, 8);
                 else if (u == 0) PO_BOUNDARY(u * (NG + 4) + NG + g2, 10);
-                else PO_BOUNDARY(u * (NG + 4) + NG + g2, 2 * NP);
+                else if (!BWD) PO_BOUNDARY(u * (NG + 4) + NG + g2, 2 * NP);
+                else if (more) PO_BOUNDARY(u * (NG + 4) + NG + g2, 10);   // (next: the next round's first group)
+                else PO_BOUNDARY(u * (NG + 4) + NG + g2, 0);
                 const f16x8* fr = reinterpret_cast<const f16x8*>(lds + sl * SLOT) + lane;
                 f16x8 A[2][4][2];
 #pragma unroll
@@ -563,8 +670,21 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         const float u2 = __uint_as_float((unsigned)(Erun - 14) << 23) * inv_w2;
         float vmax2 = 0.f;
 #pragma unroll
-        for (int a2 = 0; a2 < 8; ++a2)
-            po_epilogue<ACT>(acc2[a2], u2, par2 + 32 * a2, rs_h2, vo2 + (unsigned)(32 * a2) * ch_bytes, ch_bytes, vmax2);
+        for (int a2 = 0; a2 < 8; ++a2) {
+            if (BWD) {
+                po_epilogue_bwd<ACT>(acc2[a2], u2, par2 + 256 + 32 * a2, rs_h2, vo2 + (unsigned)(32 * a2) * ch_bytes,
+                                     ch_bytes, vmax2, mk2[a2 >> 1] >> (16 * (a2 & 1)), gs1 + 2048 + 32 * a2 * 8, quad_leader);
+            } else {
+                unsigned mw = 0u;   // forward: one mask word per pair of tiles, stored as soon as it is complete
+                if (a2 & 1) continue;
+                po_epilogue<ACT, 0>(acc2[a2], u2, par2 + 32 * a2, rs_h2, vo2 + (unsigned)(32 * a2) * ch_bytes, ch_bytes,
+                                    vmax2, mw);
+                po_epilogue<ACT, 16>(acc2[a2 + 1], u2, par2 + 32 * (a2 + 1), rs_h2, vo2 + (unsigned)(32 * (a2 + 1)) * ch_bytes,
+                                     ch_bytes, vmax2, mw);
+                if (ACT != 0 && p.m2) p.m2[((long)round * (64 * PO_WAVES) + tid) * 4 + (a2 >> 1)] = mw;
+            }
+        }
+        if constexpr (!BWD) {
         vmax2 = fmaxf(vmax2, __shfl_xor(vmax2, 32, 64));
         const int E3 = po_exp_of(vmax2);
         const float sc3 = __uint_as_float((unsigned)(268 - E3) << 23);
@@ -632,31 +752,41 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
                 const int R = 32 * jt + (r & 3) + 8 * (r >> 2) + 4 * kk;
                 if (R < 9 * p.C) Po[(long)R * HW] = Pacc[jt][r] * u3;
             }
+        }   // !BWD
     }
 #undef PO_BOUNDARY
+    if (BWD) {
+        // the workgroup's per-channel sums (LDS atomics of its four waves) -> its row of partial sums
+        __syncthreads();
+        for (int c = tid; c < 512; c += 64 * PO_WAVES) {
+            const float* g8 = gsum + c * 8;
+            p.part[(long)blockIdx.x * 512 + c] = ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
+        }
+    }
 }
 
-template <int NG, int NP, int LOGW, int ACT>
+template <int NG, int NP, int LOGW, int ACT, bool BWD>
 static int launch_po_fwd_t(const POFwdParams& p, hipStream_t s) {
     constexpr int G3 = 8 * NP;
     constexpr int SLOTF = 40 > G3 ? 40 : G3;
-    const size_t ldsz = (size_t)3 * SLOTF * 1024 + 4096 + 64 + (size_t)2 * NG * p.IPOS * 16;
-    if (ldsz > 160 * 1024 || NG * p.IPOS > PO_ITEMS * 64 * PO_WAVES) {
-        rfn_set_error("coupling_po_fwd: %zu bytes of LDS / %d staging items", ldsz, NG * p.IPOS);
+    constexpr int W = 1 << LOGW, IPOS = (PO_ROUND_PX / W + 2) * (W + 2);
+    const size_t ldsz = (size_t)3 * SLOTF * 1024 + 4096 + 64 + (size_t)2 * NG * IPOS * 16 + (BWD ? 2 * 256 * 8 * 4 : 0);
+    if (ldsz > 160 * 1024 || IPOS != p.IPOS) {
+        rfn_set_error("coupling_po: %zu bytes of LDS / %d image positions (expected %d)", ldsz, p.IPOS, IPOS);
         return -5;
     }
-    auto kern = coupling_po_fwd_kernel<NG, NP, LOGW, ACT>;
+    auto kern = coupling_po_fwd_kernel<NG, NP, LOGW, ACT, BWD>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsz);
     const int grid = p.n_rounds < 256 ? p.n_rounds : 256;
     hipLaunchKernelGGL(kern, dim3(grid), dim3(64 * PO_WAVES), ldsz, s, p);
     return 0;
 }
 
-template <int NG, int NP, int LOGW>
+template <int NG, int NP, int LOGW, bool BWD = false>
 static int launch_po_fwd(const POFwdParams& p, hipStream_t s) {
-    if (p.act == 1) return launch_po_fwd_t<NG, NP, LOGW, 1>(p, s);
-    if (p.act == 2) return launch_po_fwd_t<NG, NP, LOGW, 2>(p, s);
-    return launch_po_fwd_t<NG, NP, LOGW, 0>(p, s);
+    if (p.act == 1) return launch_po_fwd_t<NG, NP, LOGW, 1, BWD>(p, s);
+    if (p.act == 2) return launch_po_fwd_t<NG, NP, LOGW, 2, BWD>(p, s);
+    return launch_po_fwd_t<NG, NP, LOGW, 0, BWD>(p, s);
 }
 
 // shapes the fused kernel takes (the host asks before choosing this path)
@@ -670,17 +800,35 @@ extern "C" int rfn_coupling_po_supported(int N, int C, int Cc, int Hd, int H, in
     return Hd == PO_HD && pow2 && W <= PO_ROUND_PX && (H * W) % PO_ROUND_PX == 0 && inst && small;
 }
 
+/* floats per activation-mask tensor (as fp32 elements: 4 per (round, thread)) and per partial-sum buffer of the
+ * backward kernel for N frames of H x W pixels */
+extern "C" long rfn_coupling_po_mask_floats(int N, int H, int W) { return (long)N * H * W / PO_ROUND_PX * (64 * PO_WAVES) * 4; }
+extern "C" long rfn_coupling_po_bwd_part_floats(int N, int H, int W) {
+    const long r = (long)N * H * W / PO_ROUND_PX;
+    return (r < 256 ? r : 256) * 512;
+}
+
+static void po_fill_geometry(POFwdParams& p, int N, int C, int H, int W, int act) {
+    p.C = C; p.N = N; p.H = H; p.W = W; p.logW = ilog2(W); p.act = act;
+    p.rpf_shift = ilog2(H * W / PO_ROUND_PX);
+    p.n_rounds = (int)((long)N * H * W / PO_ROUND_PX);
+    p.IW = W + 2;
+    p.IPOS = (PO_ROUND_PX / W + 2) * (W + 2);
+}
+
 /* ---- a5 (fused)  AffineCoupling.net forward  (Flow/glow_modules.py:232-238 with :119-121, :139-142): see the header
  * of this file.  z: output of ActNorm+InvConv (channels [0, C/2) are read), cond: the condition tensor.
  * Outputs: h1, h2 [N,256,H,W] (saved for the backward pass) and P [N, 9C, H, W] with
- * P[tap*C + co] = Σ_c w3[co][c][tap] h2[c] -- rfn_tap_gather_f32 turns P into the Conv2dZeros output. */
+ * P[tap*C + co] = Σ_c w3[co][c][tap] h2[c] -- rfn_tap_gather_f32 turns P into the Conv2dZeros output.
+ * m1 / m2 (optional, rfn_coupling_po_mask_floats(N, H, W) floats each): 1-bit activation masks of h1 / h2 in the
+ * backward kernel's own order (rfn_coupling_po_bwd). */
 extern "C" int rfn_coupling_po_fwd(const float* z, long z_ns, const float* cond, long cond_ns, const void* wpk,
                                    const float* n1b, const float* n1l, const float* n2b, const float* n2l, float* h1,
-                                   long h1_ns, float* h2, long h2_ns, float* P, long P_ns, int N, int C, int Cc, int H,
-                                   int W, int act, rfn_stream_t stream) {
+                                   long h1_ns, float* h2, long h2_ns, float* P, long P_ns, float* m1, float* m2, int N,
+                                   int C, int Cc, int H, int W, int act, rfn_stream_t stream) {
     RFN_CHECK_ARG(z && wpk && n1b && n1l && n2b && n2l && h1 && h2 && P && (Cc == 0 || cond), -1);
     RFN_CHECK_ARG(rfn_coupling_po_supported(N, C, Cc, PO_HD, H, W), -2);
-    RFN_CHECK_ARG(((uintptr_t)wpk & 15) == 0, -3);
+    RFN_CHECK_ARG(((uintptr_t)wpk & 15) == 0 && ((uintptr_t)m1 & 15) == 0 && ((uintptr_t)m2 & 15) == 0, -3);
     RFN_CHECK_ARG(h1_ns * 4L * N < (1L << 32) && h2_ns * 4L * N < (1L << 32), -4);
     POFwdParams p;
     memset(&p, 0, sizeof(p));
@@ -688,16 +836,105 @@ extern "C" int rfn_coupling_po_fwd(const float* z, long z_ns, const float* cond,
     p.wpk = reinterpret_cast<const unsigned char*>(wpk);
     p.n1b = n1b; p.n1l = n1l; p.n2b = n2b; p.n2l = n2l;
     p.h1 = h1; p.h1_ns = h1_ns; p.h2 = h2; p.h2_ns = h2_ns; p.P = P; p.P_ns = P_ns;
-    p.Ch = C / 2; p.Cc = Cc; p.C = C; p.N = N; p.H = H; p.W = W; p.logW = ilog2(W); p.act = act;
-    p.rpf_shift = ilog2(H * W / PO_ROUND_PX);
-    p.n_rounds = (int)((long)N * H * W / PO_ROUND_PX);
-    p.IW = W + 2;
-    p.IPOS = (PO_ROUND_PX / W + 2) * (W + 2);
+    p.m1 = reinterpret_cast<unsigned*>(m1); p.m2 = reinterpret_cast<unsigned*>(m2);
+    p.Ch = C / 2; p.Cc = Cc;
+    po_fill_geometry(p, N, C, H, W, act);
     const POGeom g = po_geom(p.Ch + Cc, C);
     int rc = -4;
     if (g.NG == 3 && g.NP == 2 && W == 32) rc = launch_po_fwd<3, 2, 5>(p, (hipStream_t)stream);
     if (g.NG == 5 && g.NP == 3 && W == 16) rc = launch_po_fwd<5, 3, 4>(p, (hipStream_t)stream);
     if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+/* ---- a5 (fused, backward)  data-gradient chain of AffineCoupling.net (backward of Flow/glow_modules.py:232-238):
+ * from go = gradient at conv3's output [N, C, H, W] (dense frames, stride go_ns) to
+ *     ga2 = (conv3^T go) act'(h2) exp(n2l)   [N, 256, H, W]   gradient at conv2's output
+ *     ga1 = (w2^T ga2)   act'(h1) exp(n1l)   [N, 256, H, W]   gradient at conv1's output
+ * in ONE kernel (same machinery and arithmetic as the forward kernel: f16x3s, a wave owns 32 pixels, ga2 stays in
+ * registers on its way into the second product).  act'(.) is read from the forward kernel's 1-bit masks m_h1 / m_h2.
+ * wpk: rfn_coupling_po_pack_bwd stream.  part: rfn_coupling_po_bwd_part_floats(N, H, W) floats, WRITTEN: per-workgroup
+ * sums over pixels of ga2 ([.][0][256]) and ga1 ([.][1][256]); rfn_coupling_po_bwd_finish turns them (and the weight
+ * gradients) into the ActNorm gradients. */
+extern "C" int rfn_coupling_po_bwd_supported(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || C > 8 || H != W) return 0;
+    const bool small = (long)N * PO_HD * H * W * 4 < (1L << 32);
+    return (W == 32 || W == 16) && small;
+}
+extern "C" int rfn_coupling_po_bwd(const float* go, long go_ns, const void* wpk, const float* n1l, const float* n2l,
+                                   const float* m_h1, const float* m_h2, float* ga2, long ga2_ns, float* ga1,
+                                   long ga1_ns, float* part, int N, int C, int H, int W, int act, rfn_stream_t stream) {
+    RFN_CHECK_ARG(go && wpk && n1l && n2l && ga2 && ga1 && part && (act == 0 || (m_h1 && m_h2)), -1);
+    RFN_CHECK_ARG(rfn_coupling_po_bwd_supported(N, C, H, W), -2);
+    RFN_CHECK_ARG(((uintptr_t)wpk & 15) == 0 && ((uintptr_t)m_h1 & 15) == 0 && ((uintptr_t)m_h2 & 15) == 0, -3);
+    RFN_CHECK_ARG(ga1_ns * 4L * N < (1L << 32) && ga2_ns * 4L * N < (1L << 32), -4);
+    POFwdParams p;
+    memset(&p, 0, sizeof(p));
+    p.z = go; p.z_ns = go_ns; p.cond = go; p.cond_ns = 0;
+    p.wpk = reinterpret_cast<const unsigned char*>(wpk);
+    p.n1b = n2l; p.n1l = n2l; p.n2b = n1l; p.n2l = n1l;     // stage 1 scales by exp(l2), stage 2 by exp(l1); no biases
+    p.h1 = ga2; p.h1_ns = ga2_ns; p.h2 = ga1; p.h2_ns = ga1_ns;
+    p.m1 = reinterpret_cast<unsigned*>(const_cast<float*>(m_h2));
+    p.m2 = reinterpret_cast<unsigned*>(const_cast<float*>(m_h1));
+    p.part = part;
+    p.Ch = C; p.Cc = 0;
+    po_fill_geometry(p, N, C, H, W, act);
+    int rc = -4;
+    if (W == 32) rc = launch_po_fwd<1, 0, 5, true>(p, (hipStream_t)stream);
+    if (W == 16) rc = launch_po_fwd<1, 0, 4, true>(p, (hipStream_t)stream);
+    if (rc) return rc;
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+/* ActNorm gradients of the two hidden layers of up to 16 coupling nets (the K steps of a level) in one launch:
+ *     gnb[c] = sum over workgroups of part[.][layer][c]                      (= sum over pixels of ga)
+ *     gnl[c] = sum_k w[c][k] gw[c][k] + nb[c] gnb[c]
+ * The second line is sum over pixels of gy*y (the gradient of the ActNorm logs, glow_modules.py:38-45 backward) rewritten
+ * with y = (a + nb) exp(nl), ga = gy exp(nl) and sum_pix ga[c] a[c] = sum_k w[c][k] gw[c][k] (a = w x, gw = the weight
+ * gradient): the kernel that made ga never needs the activations themselves. */
+#define PO_FIN_MAX 16
+struct POFinishParams {
+    const float* part[PO_FIN_MAX];
+    const float* w1[PO_FIN_MAX]; const float* gw1[PO_FIN_MAX]; const float* n1b[PO_FIN_MAX];
+    const float* w2[PO_FIN_MAX]; const float* gw2[PO_FIN_MAX]; const float* n2b[PO_FIN_MAX];
+    float* out[PO_FIN_MAX];   // [4][256]: gn1b, gn1l, gn2b, gn2l
+    int nblk, K1;             // rows of `part`; elements per output channel of w1 (Cin * 9)
+};
+// grid (2 layers, n nets), 256 threads = output channels
+__global__ __launch_bounds__(256) void po_bwd_finish_kernel(const POFinishParams p) {
+    const int g = blockIdx.y, layer = blockIdx.x, c = threadIdx.x;
+    // part rows hold [stage 0 = ga2 sums (layer 2), stage 1 = ga1 sums (layer 1)]
+    const float* part = p.part[g] + (layer == 0 ? 256 : 0) + c;
+    float gb = 0.f;
+    for (int b = 0; b < p.nblk; ++b) gb += part[(long)b * 512];
+    const int K = layer == 0 ? p.K1 : PO_HD;
+    const float* w = (layer == 0 ? p.w1[g] : p.w2[g]) + (long)c * K;
+    const float* gw = (layer == 0 ? p.gw1[g] : p.gw2[g]) + (long)c * K;
+    float dot = 0.f;
+    for (int k = 0; k < K; ++k) dot = fmaf(w[k], gw[k], dot);
+    const float nb = (layer == 0 ? p.n1b[g] : p.n2b[g])[c];
+    float* out = p.out[g] + layer * 512;
+    out[c] = gb;
+    out[256 + c] = fmaf(nb, gb, dot);
+}
+extern "C" int rfn_coupling_po_bwd_finish(const float* const* part, const float* const* w1, const float* const* gw1,
+                                          const float* const* n1b, const float* const* w2, const float* const* gw2,
+                                          const float* const* n2b, float* const* out, int n, int nblk, int K1,
+                                          rfn_stream_t stream) {
+    RFN_CHECK_ARG(part && w1 && gw1 && n1b && w2 && gw2 && n2b && out && n >= 1 && n <= PO_FIN_MAX && nblk >= 1 && K1 >= 1, -1);
+    POFinishParams p;
+    memset(&p, 0, sizeof(p));
+    for (int i = 0; i < n; ++i) {
+        RFN_CHECK_ARG(part[i] && w1[i] && gw1[i] && n1b[i] && w2[i] && gw2[i] && n2b[i] && out[i], -2);
+        p.part[i] = (const float*)part[i];
+        p.w1[i] = (const float*)w1[i]; p.gw1[i] = (const float*)gw1[i]; p.n1b[i] = (const float*)n1b[i];
+        p.w2[i] = (const float*)w2[i]; p.gw2[i] = (const float*)gw2[i]; p.n2b[i] = (const float*)n2b[i];
+        p.out[i] = (float*)out[i];
+    }
+    p.nblk = nblk; p.K1 = K1;
+    hipLaunchKernelGGL(po_bwd_finish_kernel, dim3(2, n), dim3(256), 0, (hipStream_t)stream, p);
     RFN_LAUNCH_CHECK();
     return 0;
 }

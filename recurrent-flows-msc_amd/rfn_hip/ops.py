@@ -237,15 +237,36 @@ class POPackPlan:
             rec[i] = (w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), buf.data_ptr(), Cin, C)
         self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
 
+        # the backward kernel's streams (w3 transposed + mirrored, w2 transposed) for the nets whose gradient image has
+        # at most 8 channels (rfn_coupling_po_bwd_supported)
+        self.bwd_bufs = [None] * len(self.nets)
+        recb = []
+        for i, (w1, w2, w3) in enumerate(self.nets):
+            C = int(w3.shape[0])
+            if C <= 8:
+                buf = torch.empty(int(lib.rfn_coupling_po_bwd_packed_bytes(C)) // 4, device=dev, dtype=torch.float32)
+                self.bwd_bufs[i] = buf
+                recb.append((w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), buf.data_ptr(), int(w1.shape[1]), C))
+        self.n_bwd = len(recb)
+        if recb:
+            rb = np.zeros(len(recb), dtype=rec.dtype)
+            for i, r in enumerate(recb):
+                rb[i] = r
+            self.table_bwd = torch.from_numpy(rb.view(np.uint8).copy()).to(dev)
+
     def valid_for(self, nets):
         return len(nets) == len(self.nets) and all(tuple(w.data_ptr() for w in n) == p for n, p in zip(nets, self.ptrs))
 
-    def run(self):
+    def run(self, bwd=True):
+        """`bwd`: also refresh the backward streams (not needed when no gradient will be asked for)"""
         L.call("rfn_coupling_po_pack", L._c_f(self.table.data_ptr()), _i(len(self.nets)))
+        if bwd and self.n_bwd:
+            L.call("rfn_coupling_po_pack_bwd", L._c_f(self.table_bwd.data_ptr()), _i(self.n_bwd))
 
 
-def coupling_po_fwd(z, cond, wpk, n1b, n1l, n2b, n2l, C, act):
-    """h1, h2, P = fused coupling net on z[:, :C/2] | cond (rfn_coupling_po_fwd); P is the tap-expanded conv3 output."""
+def coupling_po_fwd(z, cond, wpk, n1b, n1l, n2b, n2l, C, act, want_masks=False):
+    """h1, h2, P, masks = fused coupling net on z[:, :C/2] | cond (rfn_coupling_po_fwd); P is the tap-expanded conv3
+    output; masks = (m1, m2): the 1-bit "h <= 0" masks of h1 / h2 in the backward kernel's order (None unless asked)."""
     N, _, H, W = z.shape
     Cc = 0 if cond is None else int(cond.shape[1])
     zp, zns = L.frames(z, "z")
@@ -255,13 +276,57 @@ def coupling_po_fwd(z, cond, wpk, n1b, n1l, n2b, n2l, C, act):
     P = torch.empty((N, 9 * C, H, W), device=z.device, dtype=torch.float32)
     Cin = C // 2 + Cc
     npx = float(N * H * W)
+    masks = None
+    if want_masks and act != 0:
+        nm = int(L.load().rfn_coupling_po_mask_floats(N, H, W))
+        masks = (torch.empty(nm, device=z.device, dtype=torch.float32), torch.empty(nm, device=z.device, dtype=torch.float32))
+    m1, m2 = masks if masks is not None else (None, None)
     L.call("rfn_coupling_po_fwd", zp, _l(zns), cp, _l(cns), L.dev(wpk), L.dev(n1b), L.dev(n1l), L.dev(n2b), L.dev(n2l),
-           L.dev(h1), _l(256 * H * W), L.dev(h2), _l(256 * H * W), L.dev(P), _l(9 * C * H * W), _i(N), _i(C), _i(Cc),
-           _i(H), _i(W), _i(act),
+           L.dev(h1), _l(256 * H * W), L.dev(h2), _l(256 * H * W), L.dev(P), _l(9 * C * H * W), L.dev(m1), L.dev(m2),
+           _i(N), _i(C), _i(Cc), _i(H), _i(W), _i(act),
            meta=("conv", "coupling_po_fwd_kernel", 2.0 * npx * (9 * Cin * 256 + 256 * 256 + 9 * C * 256),
                  "N%d %d+%d->256->256->9x%d %dx%d" % (N, C // 2, Cc, C, H, W),
-                 4.0 * npx * (Cin + 512 + 9 * C) + 4.0 * (9 * Cin * 256 + 65536 + 9 * C * 256)))
-    return h1, h2, P
+                 4.0 * npx * (Cin + 512 + 9 * C + (16 if masks is not None else 0))
+                 + 4.0 * (9 * Cin * 256 + 65536 + 9 * C * 256)))
+    return h1, h2, P, masks
+
+
+def coupling_po_bwd_ok(N, C, H, W):
+    return (os.environ.get("RFN_COUPLING_PO_BWD") != "0" and CONV_PRECISION == "mixed"
+            and bool(L.load().rfn_coupling_po_bwd_supported(int(N), int(C), int(H), int(W))))
+
+
+def coupling_po_bwd(go, wpk_bwd, n1l, n2l, masks, act):
+    """ga2, ga1, part = fused data-gradient chain of the coupling net from `go` (gradient at conv3's output):
+    rfn_coupling_po_bwd.  ga2 / ga1 [N,256,H,W]: gradients at the outputs of conv2 / conv1; part: per-workgroup sums."""
+    N, C, H, W = go.shape
+    gp, gns = L.frames(go, "go")
+    ga2 = torch.empty((N, 256, H, W), device=go.device, dtype=torch.float32)
+    ga1 = torch.empty((N, 256, H, W), device=go.device, dtype=torch.float32)
+    part = torch.empty(int(L.load().rfn_coupling_po_bwd_part_floats(N, H, W)), device=go.device, dtype=torch.float32)
+    m1, m2 = masks if masks is not None else (None, None)
+    npx = float(N * H * W)
+    L.call("rfn_coupling_po_bwd", gp, _l(gns), L.dev(wpk_bwd), L.dev(n1l), L.dev(n2l), L.dev(m1), L.dev(m2),
+           L.dev(ga2), _l(256 * H * W), L.dev(ga1), _l(256 * H * W), L.dev(part), _i(N), _i(C), _i(H), _i(W), _i(act),
+           meta=("conv", "coupling_po_bwd_kernel", 2.0 * npx * (9 * C * 256 + 256 * 256),
+                 "N%d %d->256->256 %dx%d dgrad chain" % (N, C, H, W),
+                 4.0 * npx * (C + 512 + (16 if masks is not None else 0)) + 4.0 * (9 * C * 256 + 65536)))
+    return ga2, ga1, part
+
+
+def coupling_po_bwd_finish(tickets):
+    """ActNorm gradients of the hidden layers of up to 16 nets per launch (rfn_coupling_po_bwd_finish); a ticket is
+    (part, w1, gw1, n1b, w2, gw2, n2b, out[4,256]); `out` is written."""
+    for i0 in range(0, len(tickets), 16):
+        tk = tickets[i0:i0 + 16]
+        cols = [L.ptr_array([t[j].detach() for t in tk], "finish") for j in range(8)]
+        nblk = int(tk[0][0].numel()) // 512
+        K1 = int(tk[0][1].numel()) // 256
+        for t in tk:
+            assert t[0].numel() == nblk * 512 and t[1].numel() == K1 * 256 and t[2].numel() == K1 * 256
+            assert t[4].numel() == 65536 and t[5].numel() == 65536 and t[2].is_contiguous() and t[5].is_contiguous()
+        L.call("rfn_coupling_po_bwd_finish", *cols, _i(len(tk)), _i(nblk), _i(K1),
+               meta=_shell("po_bwd_finish", tk[0][7], len(tk) * (nblk * 512 + 512 * K1 + 131072 + 1024) / 1024.0))
 
 
 def conv2d_raw(in1, in2, wpk, Cout, ks, ep_mode=0, p0=None, p1=None, act=0, out1=None, out2=None, cout_split=None,
@@ -686,10 +751,11 @@ def conv3x3_smallcout(x, wpk, Cout, out1, out2=None, cout_split=None, acc1=False
     return out1
 
 
-def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk):
+def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk, want_masks=False):
     """coupling network of one Glow step (glow_modules.py:232-238) on z's first channel half and `cond`.
-    Returns (h1, h2, o, P): either o (finished Conv2dZeros output) or P (its tap-expanded pre-gather form, fused forward
-    kernel) is None.  `pk`: the step's 7 pack-plan entries (see GlowStepFn.forward)."""
+    Returns (h1, h2, o, P, masks): either o (finished Conv2dZeros output) or P (its tap-expanded pre-gather form, fused
+    forward kernel) is None; masks: the fused kernel's activation masks for the fused backward kernel (or None).
+    `pk`: the step's 8 pack-plan entries (see GlowStepFn.forward)."""
     N, C, H, W = z.shape
     Ch = C // 2
     Hd = int(w1.shape[0])
@@ -705,8 +771,9 @@ def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk):
             plan = POPackPlan([(w1.detach(), w2.detach(), w3.detach())])
             plan.run()
             po = plan.bufs[0]
-        h1, h2, P = coupling_po_fwd(z, cin2, po, _f(n1b), _f(n1l), _f(n2b), _f(n2l), C, act)
-        return h1, h2, None, P
+        want = want_masks and pk[7] is not None and coupling_po_bwd_ok(N, C, H, W)
+        h1, h2, P, masks = coupling_po_fwd(z, cin2, po, _f(n1b), _f(n1l), _f(n2b), _f(n2l), C, act, want_masks=want)
+        return h1, h2, None, P, masks
     # the two deepest levels (H*W <= 16): a launch is a few thousand pixels against megabytes of weights, the
     # 3x3 convolutions go through the dense small-map kernels (bf16x3 arithmetic: only where that is allowed)
     dense = k33 and smallmap_conv_ok(H, W, Ch, Cc_, Hd, N)
@@ -723,14 +790,20 @@ def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk):
         o = smallmap_conv(h2, None, smallmap_pack(w3, H, W, False), C, 2, _f(b3), _f(l3), 0)
     else:
         o = zeros_conv_fwd(h2, w3, _f(b3), _f(l3), pk[4] if b3fwd else None, prec=fp)
-    return h1, h2, o, None
+    return h1, h2, o, None, None
 
 
-def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gcond, acc_cond, defer=None):
+def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gcond, acc_cond, defer=None,
+             n1b=None, n2b=None, masks=None, fin=None):
     """backward of the coupling network from `go` = gradient at conv3's output: returns the parameter gradients
     (gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3); the data gradient of conv1 is ADDED to gz[:, :C/2] and written (acc_cond:
     added) to gcond.  With `defer` (a dict of three lists) the weight gradients are NOT computed: their operands are
-    appended to defer["w1" | "w2" | "w3"] and None is returned in their place (grouped launch by the caller)."""
+    appended to defer["w1" | "w2" | "w3"] and None is returned in their place (grouped launch by the caller).
+    With `masks` (the fused forward kernel's activation masks; needs n1b, n2b and the step's backward stream pk[7]) the
+    data-gradient chain conv3^T -> act' -> conv2^T -> act' is ONE kernel (rfn_coupling_po_bwd) that reads no
+    activation; the four ActNorm gradients then come from the weight gradients (rfn_coupling_po_bwd_finish): a ticket
+    is appended to `fin` (the caller runs coupling_po_bwd_finish once its weight gradients exist; ticket[2] / [5] = gw1 /
+    gw2 are filled in by the caller when deferred) or, without `fin`, finished here."""
     N, C, H, W = out.shape
     Ch = C // 2
     Hd = int(w1.shape[0])
@@ -738,9 +811,18 @@ def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gc
     k1, k2, k3 = int(w1.shape[2]), int(w2.shape[2]), int(w3.shape[2])
     dfr = defer is not None and bwd_b3() and Hd % 64 == 0 and _hw(h2) % 4 == 0
     gw3 = None if dfr else zeros_conv_wgrad(h2, go, C, k3, arena)
-    w3f = pk[5] if pk[5] is not None else pack_weight(w3, True)
-    w2f = pk[3] if pk[3] is not None else pack_weight(w2, True)
-    if bwd_b3() and Hd % 64 == 0:
+    fused = (pk[7] is not None and (masks is not None or act == 0) and n1b is not None and n2b is not None
+             and k2 == 1 and k1 == 3 and k3 == 3 and Hd == 256 and coupling_po_bwd_ok(N, C, H, W))
+    w3f = w2f = None
+    if not fused:
+        w3f = pk[5] if pk[5] is not None else pack_weight(w3, True)
+        w2f = pk[3] if pk[3] is not None else pack_weight(w2, True)
+    if fused:
+        gh2, gh1, part = coupling_po_bwd(go.contiguous(), pk[7], _f(n1l), _f(n2l), masks, act)
+        gw2 = None if dfr else conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
+        o4 = torch.empty((4, 256), device=go.device, dtype=torch.float32)
+        gn1b, gn1l, gn2b, gn2l = o4[0], o4[1], o4[2], o4[3]
+    elif bwd_b3() and Hd % 64 == 0:
         # data-gradient convs with the backward of the producer's ActNorm+activation fused into their epilogue
         gh2, gn2b, gn2l = conv2d_dgrad_act(go, w3f, h2, _f(n2l), act, Hd, k3, arena)
         gw2 = None if dfr else conv2d_wgrad(h1, None, gh2, Hd, k2, arena)
@@ -756,6 +838,13 @@ def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gc
     z1 = out[:, :Ch]
     has_cond = Cc > 0
     gw1 = None if dfr else conv2d_wgrad(z1, cond if has_cond else None, gh1, Hd, k1, arena)
+    if fused:
+        ticket = [part, w1, gw1, _f(n1b), w2, gw2, _f(n2b), o4]
+        if fin is not None:
+            fin.append(ticket)
+        else:
+            assert not dfr
+            coupling_po_bwd_finish([ticket])
     if dfr:
         defer["w3"].append((h2, go))
         defer["w2"].append((h1, gh2))
@@ -821,21 +910,24 @@ class GlowStepFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, cond, Wm, an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift,
                 act, clamp_type, packs=None):
-        """`packs` (optional): (w1 fwd, w1 dgrad, w2 fwd, w2 dgrad, w3 fwd, w3 dgrad, fused-forward stream) packed
+        """`packs` (optional): (w1 fwd, w1 dgrad, w2 fwd, w2 dgrad, w3 fwd, w3 dgrad, fused-forward stream, fused-backward stream) packed
         buffers kept fresh by the caller's pack plans (entries may be None: packed on the fly); the forward entries are
         bf16x3 packs and only used where that is the forward arithmetic."""
         out = actnorm_invconv_fwd(x, _f(an_bias), _f(an_logs), Wm.detach())
-        pk = tuple(packs) + (None,) * (7 - len(packs)) if packs is not None else (None,) * 7
+        pk = tuple(packs) + (None,) * (8 - len(packs)) if packs is not None else (None,) * 8
         ctx.packs = pk
-        h1, h2, o, P = _net_fwd(out, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk)
+        h1, h2, o, P, masks = _net_fwd(out, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk,
+                                       want_masks=any(ctx.needs_input_grad))
         o, dlogdet = gather_affine_(out, o, P, _f(b3), _f(l3), _f(scale), _f(scale_shift), clamp_type)
-        ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o)
+        ctx.save_for_backward(x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o,
+                              n1b, n2b, *(masks if masks is not None else ()))
         ctx.cfg = (act, clamp_type)
         return out, dlogdet
 
     @staticmethod
     def backward(ctx, gout, gdl):
-        (x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o) = ctx.saved_tensors
+        (x, cond, Wm, an_bias, an_logs, w1, n1l, w2, n2l, w3, l3, scale, scale_shift, out, h1, h2, o, n1b, n2b) = ctx.saved_tensors[:19]
+        masks = tuple(ctx.saved_tensors[19:21]) if len(ctx.saved_tensors) > 19 else None
         act, clamp_type = ctx.cfg
         N, C, H, W = x.shape
         gout = gout.contiguous()
@@ -848,7 +940,7 @@ class GlowStepFn(torch.autograd.Function):
         gz, go, gscale, gshift, gb3, gl3 = _affine_zeros_bwd(out, o, gout, gdl, scale, scale_shift, l3, clamp_type, arena)
         gcond = torch.empty_like(cond) if Cc > 0 else torch.zeros_like(cond)
         gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3 = _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, ctx.packs,
-                                                         arena, gz, gcond, False)
+                                                         arena, gz, gcond, False, n1b=n1b, n2b=n2b, masks=masks)
         # ---- invconv + actnorm bwd
         gx, gW, gab, gal = actnorm_invconv_bwd(x, _f(an_bias), _f(an_logs), Wm.detach(), gz, arena)
         return (gx, gcond, gW, gab.view(an_bias.shape), gal.view(an_logs.shape), gw1, gn1b.view(1, -1, 1, 1),
@@ -875,8 +967,9 @@ class GlowLevelFn(torch.autograd.Function):
         assert len(flat) == STEP_NPARAM * Kn
         N, C, H, W = x.shape
         prm = [flat[STEP_NPARAM * k:STEP_NPARAM * (k + 1)] for k in range(Kn)]
-        pks = [(tuple(packs[k]) + (None,) * 7)[:7] if packs is not None and packs[k] is not None else (None,) * 7
+        pks = [(tuple(packs[k]) + (None,) * 8)[:8] if packs is not None and packs[k] is not None else (None,) * 8
                for k in range(Kn)]
+        want_masks = any(ctx.needs_input_grad)
         Wd = Wst.detach().contiguous()
         dl = torch.zeros(N, device=x.device, dtype=torch.float32)
         xp, xns = L.frames(x, "x")
@@ -886,10 +979,11 @@ class GlowLevelFn(torch.autograd.Function):
         L.call("rfn_glow_shell_fwd_f32", xp, _l(xns), None, None, _l(0), None, None, None, None, None, L.dev(dl), _i(0),
                L.dev(ab0), L.dev(al0), L.dev(Wd[0]), zp, _l(zns), _i(1), _i(N), _i(C), _i(H), _i(W),
                meta=_shell("glow_shell_fwd", x, 2))
-        outs, h1s, h2s, os_ = [], [], [], []
+        outs, h1s, h2s, os_, mks = [], [], [], [], []
         for k in range(Kn):
             (_, _, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift) = prm[k]
-            h1, h2, o, P = _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pks[k])
+            h1, h2, o, P, masks = _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pks[k], want_masks)
+            mks.append(masks)
             last = k == Kn - 1
             zn = None if last else torch.empty_like(z)
             znp, znns = (None, 0) if last else L.frames(zn, "znext")
@@ -911,19 +1005,23 @@ class GlowLevelFn(torch.autograd.Function):
             h2s.append(h2)
             os_.append(o)
             z = zn
-        ctx.save_for_backward(x, cond, Wst, *flat, *outs, *h1s, *h2s, *os_)
-        ctx.cfg = (act, clamp_type, Kn, pks)
+        has_masks = all(m is not None for m in mks)
+        ctx.save_for_backward(x, cond, Wst, *flat, *outs, *h1s, *h2s, *os_,
+                              *([m[0] for m in mks] + [m[1] for m in mks] if has_masks else []))
+        ctx.cfg = (act, clamp_type, Kn, pks, has_masks)
         return outs[-1], dl
 
     @staticmethod
     def backward(ctx, gout, gdl):
-        act, clamp_type, Kn, pks = ctx.cfg
+        act, clamp_type, Kn, pks, has_masks = ctx.cfg
         sv = ctx.saved_tensors
         x, cond, Wst = sv[0], sv[1], sv[2]
         nf = STEP_NPARAM * Kn
         flat = sv[3:3 + nf]
         rest = sv[3 + nf:]
         outs, h1s, h2s, os_ = (rest[i * Kn:(i + 1) * Kn] for i in range(4))
+        mks = [(rest[4 * Kn + k], rest[5 * Kn + k]) for k in range(Kn)] if has_masks else [None] * Kn
+        fin = []   # ActNorm-gradient tickets of the fused backward kernel, finished in one launch at the end
         prm = [flat[STEP_NPARAM * k:STEP_NPARAM * (k + 1)] for k in range(Kn)]
         N, C, H, W = x.shape
         Ch, HW = C // 2, H * W
@@ -954,8 +1052,12 @@ class GlowLevelFn(torch.autograd.Function):
                  else None)
         for k in range(Kn - 1, -1, -1):
             (an_bias, an_logs, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, scale, scale_shift) = prm[k]
+            nfin = len(fin)
             gw1, gn1b, gn1l, gw2, gn2b, gn2l, gw3 = _net_bwd(go, outs[k], cond, h1s[k], h2s[k], w1, n1l, w2, n2l, w3, act,
-                                                             pks[k], arena, gz, gcond, k != Kn - 1, defer)
+                                                             pks[k], arena, gz, gcond, k != Kn - 1, defer,
+                                                             n1b=n1b, n2b=n2b, masks=mks[k], fin=fin)
+            if len(fin) > nfin:
+                fin[-1].append(k)   # the step whose (possibly deferred) weight gradients the ticket needs
             base = STEP_NPARAM * k
             grads[base + 2:base + 13] = [gw1, gn1b.view(1, -1, 1, 1), gn1l.view(n1l.shape), gw2, gn2b.view(1, -1, 1, 1),
                                          gn2l.view(n2l.shape), gw3, gb3, gl3.view(l3.shape),
@@ -1006,6 +1108,11 @@ class GlowLevelFn(torch.autograd.Function):
             for k in range(Kn):
                 base = STEP_NPARAM * k
                 grads[base + 2], grads[base + 5], grads[base + 8] = g1[k], g2[k], g3[k]
+        if fin:
+            for t in fin:
+                base = STEP_NPARAM * t.pop()
+                t[2], t[5] = grads[base + 2], grads[base + 5]
+            coupling_po_bwd_finish(fin)
         return (gx, gcond, gWst, None, None, None) + tuple(grads)
 
 
@@ -1036,7 +1143,7 @@ class GlowStepRevFn(torch.autograd.Function):
                 plan = POPackPlan([(w1.detach(), w2.detach(), w3.detach())])
                 plan.run()
                 return plan.bufs[0]
-            _, _, P = coupling_po_fwd(z, cin2, cached("po", make_po), f(n1b), f(n1l), f(n2b), f(n2l), C, act)
+            _, _, P, _ = coupling_po_fwd(z, cin2, cached("po", make_po), f(n1b), f(n1l), f(n2b), f(n2l), C, act)
             o = torch.empty((N, C, H, W), device=x.device, dtype=torch.float32)
             b3f, l3f = f(b3), f(l3)
             L.call("rfn_tap_gather_f32", L.dev(P), L.dev(b3f), L.dev(l3f), L.dev(o), _i(N), _i(C), _i(H), _i(W))

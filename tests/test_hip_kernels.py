@@ -590,7 +590,7 @@ def test_coupling_po_fused_forward(K, N, C, Cc, S, act, conv_precision):
     w1c, w2c, w3c = cu(w1), cu(w2), cu(w3)
     plan = K.POPackPlan([(w1c, w2c, w3c)])
     plan.run()
-    h1, h2, P = K.coupling_po_fwd(cu(z), cu(cond), plan.bufs[0], cu(n1b), cu(n1l), cu(n2b), cu(n2l), C, act)
+    h1, h2, P, _ = K.coupling_po_fwd(cu(z), cu(cond), plan.bufs[0], cu(n1b), cu(n1l), cu(n2b), cu(n2l), C, act)
     o = torch.empty((N, C, S, S), device="cuda")
     from rfn_hip import lib as L
     import ctypes
@@ -601,3 +601,69 @@ def test_coupling_po_fused_forward(K, N, C, Cc, S, act, conv_precision):
     assert relerr(h1, h1r) < 2e-5
     assert relerr(h2, h2r) < 2e-5
     assert relerr(o, orf) < 2e-5
+
+
+@pytest.mark.parametrize("N,C,Cc,S,act", [(2, 4, 16, 32, 1), (4, 8, 32, 16, 2), (41, 4, 16, 32, 1), (3, 8, 32, 16, 1)])
+def test_coupling_po_fused_backward(K, N, C, Cc, S, act, conv_precision):
+    """the fused data-gradient chain of the coupling net (csrc/coupling_po.hip, BWD instantiation: conv3^T -> act' ->
+    conv2^T -> act', the intermediate gradient handed over in registers, act' read from the forward kernel's 1-bit masks)
+    against torch autograd in fp64 on the CPU: the gradients at the outputs of conv2 and conv1 (ga2, ga1), and the four
+    ActNorm gradients that rfn_coupling_po_bwd_finish derives from the per-workgroup sums and the weight gradients
+    (gnl[c] = sum_k w[c][k] gw[c][k] + nb[c] gnb[c]).  N=41 frames of 32x32 = 328 rounds: more than one per workgroup.
+    Tolerance 2e-5 of the tensor's largest magnitude for the data gradients (f16x3s arithmetic), 1e-4 for the ActNorm
+    gradients (they inherit the weight gradients' bf16x3 arithmetic)."""
+    if conv_precision != "mixed":
+        pytest.skip("the fused kernels are the path of the 'mixed' arithmetic")
+    g = torch.Generator().manual_seed(23)
+    Ch, Cin = C // 2, C // 2 + Cc
+    z = torch.randn(N, C, S, S, generator=g)
+    cond = torch.randn(N, Cc, S, S, generator=g)
+    w1 = (torch.randn(256, Cin, 3, 3, generator=g) * 0.05)
+    w2 = (torch.randn(256, 256, 1, 1, generator=g) * 0.05)
+    w3 = (torch.randn(C, 256, 3, 3, generator=g) * 0.05)
+    n1b, n1l = torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
+    n2b, n2l = torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
+    go = torch.randn(N, C, S, S, generator=g)
+    actf = (lambda t: F.relu(t)) if act == 1 else (lambda t: F.leaky_relu(t, 0.2))
+    d = lambda t: t.double().clone().requires_grad_(True)
+    w1d, w2d, w3d, n1bd, n1ld, n2bd, n2ld = d(w1), d(w2), d(w3), d(n1b), d(n1l), d(n2b), d(n2l)
+    xin = torch.cat((z[:, :Ch], cond), 1).double()
+    a1 = F.conv2d(xin, w1d, padding=1)
+    a1.retain_grad()
+    h1r = actf((a1 + n1bd.view(1, -1, 1, 1)) * n1ld.exp().view(1, -1, 1, 1))
+    a2 = F.conv2d(h1r, w2d)
+    a2.retain_grad()
+    h2r = actf((a2 + n2bd.view(1, -1, 1, 1)) * n2ld.exp().view(1, -1, 1, 1))
+    F.conv2d(h2r, w3d, padding=1).backward(go.double())
+    assert K.coupling_po_ok(N, C, Cc, 256, S, S, w1, w3) and K.coupling_po_bwd_ok(N, C, S, S)
+    w1c, w2c, w3c = cu(w1), cu(w2), cu(w3)
+    plan = K.POPackPlan([(w1c, w2c, w3c)])
+    plan.run()
+    assert plan.bwd_bufs[0] is not None
+    n1bc, n1lc, n2bc, n2lc = cu(n1b), cu(n1l), cu(n2b), cu(n2l)
+    h1, h2, P, masks = K.coupling_po_fwd(cu(z), cu(cond), plan.bufs[0], n1bc, n1lc, n2bc, n2lc, C, act, want_masks=True)
+    assert masks is not None
+    ga2, ga1, part = K.coupling_po_bwd(cu(go), plan.bwd_bufs[0], n1lc, n2lc, masks, act)
+    torch.cuda.synchronize()
+
+    def check(got, ref, y_ref):
+        """2e-5 of the largest magnitude everywhere -- except where the reference's pre-activation sits within 1e-5 of
+        the activation's kink: there the GPU's own (fp32-grade) forward value may fall on the other side, and act' is
+        discontinuous; such elements must be a vanishing fraction"""
+        e = (got.detach().cpu().double() - ref).abs()
+        bad = e > 2e-5 * float(ref.abs().max())
+        near_kink = y_ref.detach().abs() < 1e-5 * float(y_ref.abs().max())
+        assert not bool((bad & ~near_kink).any()), float(e[bad & ~near_kink].max())
+        assert int(bad.sum()) <= max(2, got.numel() // 1000000)
+
+    check(ga2, a2.grad, a2.detach() + n2bd.detach().view(1, -1, 1, 1))
+    check(ga1, a1.grad, a1.detach() + n1bd.detach().view(1, -1, 1, 1))
+    # the weight gradients as the product computes them, then the finishing launch
+    gw2 = K.conv2d_wgrad(h1, None, ga2, 256, 1)
+    gw1 = K.conv2d_wgrad(cu(z)[:, :Ch], cu(cond), ga1, 256, 3)
+    assert relerr(gw2, w2d.grad) < 1e-4 and relerr(gw1, w1d.grad) < 1e-4
+    out = torch.empty((4, 256), device="cuda")
+    K.coupling_po_bwd_finish([[part, w1c, gw1.contiguous(), n1bc, w2c, gw2.contiguous(), n2bc, out]])
+    torch.cuda.synchronize()
+    for got, ref in zip(out, (n1bd.grad, n1ld.grad, n2bd.grad, n2ld.grad)):
+        assert relerr(got, ref) < 1e-4
