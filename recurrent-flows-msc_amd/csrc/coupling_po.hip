@@ -295,19 +295,22 @@ __device__ __forceinline__ void po_epilogue(f32x16& acc, const float u, const fl
 
 // Backward counterpart: acc holds the gradient wrt the layer's activated output h = act((a + b) exp(l)); the tile
 // becomes ga = acc * u * act'(.) * exp(l) = the gradient wrt the convolution output a (what the weight gradient and the
-// next data gradient consume), is stored, and its sum over the wave's pixels is added to the workgroup's per-channel sums
-// in LDS (gs -> slot [channel of register 0][quad of this lane]; 8 slots per channel): two DPP adds bring the four
-// pixels of a lane quad together, one lane per quad issues the LDS atomic.  (Sum over pixels of ga = gradient of the
-// ActNorm bias; the gradient of its logs follows from the weight gradient, see po_bwd_finish_kernel.)
+// next data gradient consume) and is stored.  Its sum over pixels (the ActNorm bias gradient; the gradient of the logs
+// follows from the weight gradient, see po_bwd_finish_kernel) is gathered without leaving the registers: a two-level
+// butterfly over the lanes of a quad turns each group of four registers into ONE register whose lane j of the quad
+// holds the quad's sum of register j (9 VALU per 4 values), which is added to the running sums psum[4] of this tile
+// (kept across all rounds of the workgroup; reduced over the quads once, at the end of the kernel).
+// (A first version added the quad sums to LDS with ds_add_f32: an LDS float atomic costs the CU about 32 cycles per
+// wave instruction however few lanes are active -- 1024 of them per round doubled the round time.)
 template <int ACT>
 __device__ __forceinline__ void po_epilogue_bwd(f32x16& acc, const float u, const float* pe,
                                                 const __amdgpu_buffer_rsrc_t rsrc, const unsigned voff,
-                                                const unsigned ch_bytes, float& vmax, const unsigned mbits, float* gs,
-                                                const bool quad_leader) {
-    float sum[16];
+                                                const unsigned ch_bytes, float& vmax, const unsigned mbits,
+                                                float (&psum)[4], const bool bit0, const bool bit1) {
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
         const f32x4 e4 = *reinterpret_cast<const f32x4*>(pe + 8 * q);
+        float t4[4];
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
             float t = acc[4 * q + i] * u * e4[i];
@@ -315,17 +318,18 @@ __device__ __forceinline__ void po_epilogue_bwd(f32x16& acc, const float u, cons
             if (ACT == 1) t = off ? 0.f : t;
             if (ACT == 2) t = off ? 0.2f * t : t;
             acc[4 * q + i] = t;
+            t4[i] = t;
             vmax = fmaxf(vmax, fabsf(t));
             __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(t), rsrc, voff, (8 * q + i) * ch_bytes, 0);
-            float v = t;
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, true));  // quad_perm [1,0,3,2]
-            v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, true));  // quad_perm [2,3,0,1]
-            sum[4 * q + i] = v;
         }
-    }
-    if (quad_leader) {
-#pragma unroll
-        for (int r = 0; r < 16; ++r) atomicAdd(gs + (8 * (r >> 2) + (r & 3)) * 8, sum[r]);
+        // lane pair (l, l^1): even lanes gather register 0 (2), odd lanes register 1 (3)
+        float s01 = (bit0 ? t4[1] : t4[0]) +
+                    __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bit0 ? t4[0] : t4[1]), 0xB1, 0xF, 0xF, true));
+        float s23 = (bit0 ? t4[3] : t4[2]) +
+                    __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bit0 ? t4[2] : t4[3]), 0xB1, 0xF, 0xF, true));
+        // lane pairs (l, l^2): lanes 0,1 of the quad keep registers 0,1, lanes 2,3 registers 2,3
+        psum[q] += (bit1 ? s23 : s01) +
+                   __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(bit1 ? s01 : s23), 0x4E, 0xF, 0xF, true));
     }
 }
 
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
     float* par = reinterpret_cast<float*>(lds + 3 * SLOT);                 // [4][256]: b1, exp(l1), b2, exp(l2)
     float* red = par + 1024;                                               // [8] block reductions
     f16x8* img = reinterpret_cast<f16x8*>(lds + 3 * SLOT + 4096 + 64);      // [plane 2][NG][IPOS]
-    float* gsum = reinterpret_cast<float*>(lds + 3 * SLOT + 4096 + 64 + 2 * NG * IPOS * 16);   // BWD: [2][256][8]
+    float* gsum = reinterpret_cast<float*>(lds + 3 * SLOT + 4096 + 64 + 2 * NG * IPOS * 16);   // BWD: [4 waves][2][256]
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int l31 = lane & 31, kk = lane >> 5;
@@ -373,8 +377,14 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         par[512 + c] = BWD ? 0.f : p.n2b[c];
         par[768 + c] = expf(p.n2l[c]);
     }
-    if (BWD)
-        for (int c = tid; c < 2 * 256 * 8; c += 64 * PO_WAVES) gsum[c] = 0.f;
+    // BWD: running per-channel sums of the two stages' outputs, packed: psN[a][q] lane j of a quad <-> channel
+    // 32 a + 4 kk + 8 q + j, summed over the quad's pixels of every round of this workgroup
+    float ps1[BWD ? 8 : 1][4], ps2[BWD ? 8 : 1][4];
+#pragma unroll
+    for (int a = 0; a < (BWD ? 8 : 1); ++a)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) ps1[a][q] = ps2[a][q] = 0.f;
+    const bool lbit0 = lane & 1, lbit1 = lane & 2;
     const float* hdr = reinterpret_cast<const float*>(p.wpk);
     const float inv_w1 = hdr[0], inv_w2 = hdr[1], inv_w3 = hdr[2];
     __syncthreads();
@@ -515,8 +525,6 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
             mk1[0] = a_.x; mk1[1] = a_.y; mk1[2] = a_.z; mk1[3] = a_.w;
             mk2[0] = b_.x; mk2[1] = b_.y; mk2[2] = b_.z; mk2[3] = b_.w;
         }
-        const bool quad_leader = (lane & 3) == 0;
-        float* gs1 = gsum + (4 * kk) * 8 + (l31 >> 2);   // + 32 a * 8 per tile; second stage 2048 floats further
 
         f32x16 acc2[8];   // conv2 accumulators = h2 (all 256 channels of this lane's pixel half)
 #pragma unroll
@@ -586,7 +594,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
                 const int a = 4 * u + t;   // tile: mask word a >> 1, bits 16 (a & 1) ..
                 if (BWD)
                     po_epilogue_bwd<ACT>(Q[t], u1, par1 + 256 + 32 * a, rs_h1, vo1 + (unsigned)(32 * a) * ch_bytes, ch_bytes,
-                                         vmax, mk1[a >> 1] >> (16 * (a & 1)), gs1 + 32 * a * 8, quad_leader);
+                                         vmax, mk1[a >> 1] >> (16 * (a & 1)), ps1[BWD ? a : 0], lbit0, lbit1);
                 else if (t & 1)
                     po_epilogue<ACT, 16>(Q[t], u1, par1 + 32 * a, rs_h1, vo1 + (unsigned)(32 * a) * ch_bytes, ch_bytes,
                                          vmax, mq[t >> 1]);
@@ -673,7 +681,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         for (int a2 = 0; a2 < 8; ++a2) {
             if (BWD) {
                 po_epilogue_bwd<ACT>(acc2[a2], u2, par2 + 256 + 32 * a2, rs_h2, vo2 + (unsigned)(32 * a2) * ch_bytes,
-                                     ch_bytes, vmax2, mk2[a2 >> 1] >> (16 * (a2 & 1)), gs1 + 2048 + 32 * a2 * 8, quad_leader);
+                                     ch_bytes, vmax2, mk2[a2 >> 1] >> (16 * (a2 & 1)), ps2[BWD ? a2 : 0], lbit0, lbit1);
             } else {
                 unsigned mw = 0u;   // forward: one mask word per pair of tiles, stored as soon as it is complete
                 if (a2 & 1) continue;
@@ -756,12 +764,23 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
     }
 #undef PO_BOUNDARY
     if (BWD) {
-        // the workgroup's per-channel sums (LDS atomics of its four waves) -> its row of partial sums
+        // running sums: over the 8 quads of each 32-lane half (two rotations inside the 16-lane rows, then the other
+        // row), each wave into its own LDS row, then the four rows together -> the workgroup's row of partial sums
+#pragma unroll
+        for (int st = 0; st < 2; ++st)
+#pragma unroll
+            for (int a = 0; a < 8; ++a)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    float v = st == 0 ? ps1[a][q] : ps2[a][q];
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x124, 0xF, 0xF, true));  // row_ror:4
+                    v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x128, 0xF, 0xF, true));  // row_ror:8
+                    v += __shfl_xor(v, 16, 64);
+                    if (l31 < 4) gsum[(wave * 2 + st) * 256 + 32 * a + 4 * kk + 8 * q + l31] = v;
+                }
         __syncthreads();
-        for (int c = tid; c < 512; c += 64 * PO_WAVES) {
-            const float* g8 = gsum + c * 8;
-            p.part[(long)blockIdx.x * 512 + c] = ((g8[0] + g8[1]) + (g8[2] + g8[3])) + ((g8[4] + g8[5]) + (g8[6] + g8[7]));
-        }
+        for (int c = tid; c < 512; c += 64 * PO_WAVES)
+            p.part[(long)blockIdx.x * 512 + c] = (gsum[c] + gsum[512 + c]) + (gsum[1024 + c] + gsum[1536 + c]);
     }
 }
 
@@ -770,7 +789,7 @@ static int launch_po_fwd_t(const POFwdParams& p, hipStream_t s) {
     constexpr int G3 = 8 * NP;
     constexpr int SLOTF = 40 > G3 ? 40 : G3;
     constexpr int W = 1 << LOGW, IPOS = (PO_ROUND_PX / W + 2) * (W + 2);
-    const size_t ldsz = (size_t)3 * SLOTF * 1024 + 4096 + 64 + (size_t)2 * NG * IPOS * 16 + (BWD ? 2 * 256 * 8 * 4 : 0);
+    const size_t ldsz = (size_t)3 * SLOTF * 1024 + 4096 + 64 + (size_t)2 * NG * IPOS * 16 + (BWD ? PO_WAVES * 512 * 4 : 0);
     if (ldsz > 160 * 1024 || IPOS != p.IPOS) {
         rfn_set_error("coupling_po: %zu bytes of LDS / %d image positions (expected %d)", ldsz, p.IPOS, IPOS);
         return -5;
@@ -902,22 +921,37 @@ struct POFinishParams {
     float* out[PO_FIN_MAX];   // [4][256]: gn1b, gn1l, gn2b, gn2l
     int nblk, K1;             // rows of `part`; elements per output channel of w1 (Cin * 9)
 };
-// grid (2 layers, n nets), 256 threads = output channels
+// grid (8 groups of 32 channels, 2 layers, n nets), 256 threads
 __global__ __launch_bounds__(256) void po_bwd_finish_kernel(const POFinishParams p) {
-    const int g = blockIdx.y, layer = blockIdx.x, c = threadIdx.x;
-    // part rows hold [stage 0 = ga2 sums (layer 2), stage 1 = ga1 sums (layer 1)]
-    const float* part = p.part[g] + (layer == 0 ? 256 : 0) + c;
-    float gb = 0.f;
-    for (int b = 0; b < p.nblk; ++b) gb += part[(long)b * 512];
+    __shared__ float red[8][32];
+    const int g = blockIdx.z, layer = blockIdx.y, c0 = 32 * blockIdx.x, tid = threadIdx.x;
+    // part rows hold [stage 0 = ga2 sums (layer 2), stage 1 = ga1 sums (layer 1)]: 8 row-slices x 32 channels
+    {
+        const int bl = tid >> 5, c = tid & 31;
+        const float* part = p.part[g] + (layer == 0 ? 256 : 0) + c0 + c;
+        float sgb = 0.f;
+        for (int b = bl; b < p.nblk; b += 8) sgb += part[(long)b * 512];
+        red[bl][c] = sgb;
+    }
+    __syncthreads();
+    const int wave = tid >> 6, lane = tid & 63;
     const int K = layer == 0 ? p.K1 : PO_HD;
-    const float* w = (layer == 0 ? p.w1[g] : p.w2[g]) + (long)c * K;
-    const float* gw = (layer == 0 ? p.gw1[g] : p.gw2[g]) + (long)c * K;
-    float dot = 0.f;
-    for (int k = 0; k < K; ++k) dot = fmaf(w[k], gw[k], dot);
-    const float nb = (layer == 0 ? p.n1b[g] : p.n2b[g])[c];
+    const float* wb = layer == 0 ? p.w1[g] : p.w2[g];
+    const float* gwb = layer == 0 ? p.gw1[g] : p.gw2[g];
+    const float* nbp = layer == 0 ? p.n1b[g] : p.n2b[g];
     float* out = p.out[g] + layer * 512;
-    out[c] = gb;
-    out[256 + c] = fmaf(nb, gb, dot);
+    for (int ci = wave; ci < 32; ci += 4) {     // a wave per channel: coalesced rows of w and gw
+        const int c = c0 + ci;
+        float dot = 0.f;
+        for (int k = lane; k < K; k += 64) dot = fmaf(wb[(long)c * K + k], gwb[(long)c * K + k], dot);
+        dot = wave_sum_dpp(dot);
+        if (lane == 0) {
+            const float gb = ((red[0][ci] + red[1][ci]) + (red[2][ci] + red[3][ci])) +
+                             ((red[4][ci] + red[5][ci]) + (red[6][ci] + red[7][ci]));
+            out[c] = gb;
+            out[256 + c] = fmaf(nbp[c], gb, dot);
+        }
+    }
 }
 extern "C" int rfn_coupling_po_bwd_finish(const float* const* part, const float* const* w1, const float* const* gw1,
                                           const float* const* n1b, const float* const* w2, const float* const* gw2,
@@ -934,7 +968,7 @@ extern "C" int rfn_coupling_po_bwd_finish(const float* const* part, const float*
         p.out[i] = (float*)out[i];
     }
     p.nblk = nblk; p.K1 = K1;
-    hipLaunchKernelGGL(po_bwd_finish_kernel, dim3(2, n), dim3(256), 0, (hipStream_t)stream, p);
+    hipLaunchKernelGGL(po_bwd_finish_kernel, dim3(8, 2, n), dim3(256), 0, (hipStream_t)stream, p);
     RFN_LAUNCH_CHECK();
     return 0;
 }
