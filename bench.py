@@ -211,9 +211,9 @@ def parity_check(device, T=10, scales=(0.003, 0.01, 0.1)):
     """GPU loss vs CPU oracle on the canonical architecture, same weights and noise: B=2, T=10 (a 9-step rollout of the
     latent recurrence and 18 modeled frames through the 50-step flow), every flow parameter perturbed by N(0, s^2) for
     s = 0.003, 0.01 and 0.1 after the data dependent init (Conv2dZeros / realnvp scales start at exactly zero, which would make
-    the coupling nets irrelevant to the result).  Returns the bits/dim of both sides per scale (GPU: median of three
-    evaluations) and the worst relative error over the scales at which the fp32 oracle is finite; the split-precision
-    convolutions stay the headline only while that error is within north_star's 1e-4."""
+    the coupling nets irrelevant to the result).  Returns the bits/dim of both sides per scale and the worst relative error
+    over the scales at which the fp32 oracle is finite; the split-precision convolutions stay the headline only while
+    that error is within north_star's 1e-4.  (`reproducible`: a second evaluation gave the same bits.)"""
     import main_rfn
     from RFN import RFN
     from oracle import rfn_oracle as O
@@ -234,11 +234,11 @@ def parity_check(device, T=10, scales=(0.003, 0.01, 0.1)):
             gp = torch.Generator().manual_seed(3)
             for prm in m.flow.parameters():
                 prm.add_(s_ * torch.randn(prm.shape, generator=gp).to(device))
-            # three evaluations of the same weights: the split-K convolutions of the deep levels combine partial sums
-            # with float atomics in a run-dependent order, and at s = 0.01 the flow amplifies those last-bit
-            # differences to the 1e-5 level -- the MEDIAN is the figure of merit, all three are reported
+            # the forward pass has no order-dependent float atomics any more (round 3: split-K slices and per-frame
+            # log-det partials are added in a fixed order, the feature convolutions left MIOpen's split-K kernels): ONE
+            # evaluation is the figure of merit; a second one only feeds the `reproducible` flag
             gpu_runs = []
-            for _ in range(3):
+            for _ in range(2):
                 kl_fb, kl, nll = m.loss(x.to(device), 0, draws=draws)
                 gpu_runs.append(O.bits_per_dim(kl.cpu(), nll.cpu(), x.shape[2:], T - 1))
         sd = {k: v.detach().cpu().clone() for k, v in m.state_dict().items()}
@@ -246,11 +246,12 @@ def parity_check(device, T=10, scales=(0.003, 0.01, 0.1)):
             r = O.rfn_loss(sd, vars(args), x, draws, True)
         bpd_ref = O.bits_per_dim(r[1], r[2], x.shape[2:], T - 1)
         finite = bpd_ref == bpd_ref and abs(bpd_ref) != float("inf")
-        errs = sorted(abs(v - bpd_ref) / abs(bpd_ref) for v in gpu_runs) if finite else None
-        bpd_gpu = sorted(gpu_runs)[1]
+        errs = [abs(v - bpd_ref) / abs(bpd_ref) for v in gpu_runs] if finite else None
+        bpd_gpu = gpu_runs[0]
         res["cases"].append({"perturbation": s_, "bits_per_dim_gpu": bpd_gpu if bpd_gpu == bpd_gpu else None,
                              "bits_per_dim_oracle": bpd_ref if finite else None, "oracle_finite": finite,
-                             "rel_err": errs[1] if finite else None, "rel_err_runs": errs})
+                             "rel_err": max(errs) if finite else None,
+                             "reproducible": gpu_runs[0] == gpu_runs[1] or gpu_runs[0] != gpu_runs[0]})
         del m
     # a perturbation at which the fp32 reference arithmetic itself overflows (0.1: the oracle returns nan) is no
     # parity point; it is reported and left out of the maximum

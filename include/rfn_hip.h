@@ -10,7 +10,12 @@
  *   - every tensor is fp32, NCHW, device memory, 4-byte aligned; "ns" arguments are the frame (dim-0) stride in
  *     ELEMENTS, so a channel-slice view of a bigger tensor can be passed without a copy; the channel stride is H*W;
  *   - N is the number of frames in the launch (the host time-batches B*(T-1) frames), HW = H*W;
- *   - all functions enqueue on `stream` (a hipStream_t passed as void*) and never synchronise or allocate;
+ *   - all functions enqueue on `stream` (a hipStream_t passed as void*) and never synchronise; the only allocation the
+ *     library makes is ONE grow-only scratch buffer per device for the split-K convolutions (few-pixel shapes: the K
+ *     slices write partial outputs there and a second kernel adds them in a fixed order -- no float atomics, results are
+ *     bit-reproducible).  It grows on first use of a larger shape (hipMalloc; refused with an error while the stream is
+ *     being captured into a hipGraph: run the shape eagerly once first) and serves every stream of the device, so
+ *     split-K convolutions on DIFFERENT streams of one device must not overlap in time;
  *   - return value: 0 on success, otherwise a hipError_t / negative argument-check code; rfn_last_error() gives text;
  *   - global state: the (thread-local) last-error string, and five developer knobs that the kernel selectors read ONCE
  *     from the environment at their first call and then keep for the life of the process: RFN_CONV_WS (0: no
@@ -53,7 +58,7 @@ int rfn_actnorm_invconv_bwd_f32(const float* x, long x_ns, const float* bias, co
                                 float* glogs, int N, int C, int HW, rfn_stream_t stream);
 /* ---- a4  InvConv.get_weight for the K steps of a flow level  (glow_modules.py:178-207, forward direction):
  *   W[k] = P[k] (lower[k] o tril(-1) + I)(upper[k] o triu(+1) + diag(sign_s[k] * exp(log_s[k]))),  W is [K][C][C];
- *   *logdet += H*W * sum_k sum(log_s[k])   (float atomics: the caller zeroes it).
+ *   *logdet  = H*W * sum_k sum(log_s[k])   (written; the K steps are added in order by one workgroup: no atomics).
  * The five parameter arguments are HOST arrays of K device pointers (one per step: no stacking copies); K <=
  * RFN_INVCONV_MAX_STEPS, C <= RFN_INVCONV_MAX_CHANNELS (three C x C matrices in LDS).  Backward: from gW [K][C][C] and gc (gradient of the scalar, may be NULL) to
  * g_lower, g_upper [K][C][C] (zero outside their triangles) and g_log_s [K][C]. */
@@ -203,13 +208,19 @@ int rfn_affine_zeros_bwd_f32(const float* zout, long zout_ns, const float* o, lo
                              float* gb3, float* gl3, int clamp_type, int N, int C, int HW, rfn_stream_t stream);
 
 /* ---- a6 shell BETWEEN two consecutive Glow steps of a level, one launch each way (Flow/glow.py:31-36 unrolled over
- * the K steps of a level).  Forward: the coupling tail of step k (as rfn_gather_affine_f32, but logdet [N] is
- * ACCUMULATED) then, when Wm != NULL, the ActNorm + InvConv head of step k+1: znext = Wm ((z' + bias) * exp(logs)).
- * With P == o_in == NULL only the head runs (first step of a level; z is then read only). */
+ * the K steps of a level).  Forward: the coupling tail of step k (as rfn_gather_affine_f32) then, when Wm != NULL, the
+ * ActNorm + InvConv head of step k+1: znext = Wm ((z' + bias) * exp(logs)).  With P == o_in == NULL only the head runs
+ * (first step of a level; z is then read only).
+ * Log-det WITHOUT float atomics (a forward pass is bit-reproducible): `logdet` is this launch's buffer of per-workgroup
+ * partial sums (rfn_glow_shell_fwd_ld_floats(N, C, H, W) floats, WRITTEN); rfn_logdet_reduce_f32 adds the partials of
+ * n_launch consecutive such buffers per frame in a fixed order into logdet [N] (accumulate = 1: added to it). */
 int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const float* o_in, long o_ns, const float* b3,
                            const float* l3, float* o_out, const float* scale, const float* scale_shift, float* logdet,
                            int clamp_type, const float* bias, const float* logs, const float* Wm, float* znext,
                            long znext_ns, int ld_const, int N, int C, int H, int W, rfn_stream_t stream);
+long rfn_glow_shell_fwd_ld_floats(int N, int C, int H, int W);
+int rfn_logdet_reduce_f32(const float* part, int n_launch, float* logdet, int accumulate, int N, int C, int H, int W,
+                          rfn_stream_t stream);
 /* (ld_const = 1: the head also adds its ActNorm's parameter-only log-det term H*W * sum_c logs[c] to logdet[n],
  * glow_modules.py:47-52; the backward kernels below then add H*W * sum_n glogdet[n] to glogs.) */
 /* Backward: rfn_actnorm_invconv_bwd_f32 of step k+1 (x = its input = step k's output, gz = gradient wrt its

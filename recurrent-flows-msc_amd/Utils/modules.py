@@ -144,10 +144,26 @@ def run_time_batched(seq, x, steps):
                 i += 2 if act else 1
                 continue
             x = per_step_batchnorm(bn, x, steps)
+        elif _own_conv(m, x):
+            # The 3x3 convolutions of the extractor / upscaler run on the package's own kernels, not on MIOpen: on
+            # few-pixel problems (the 8x8 .. 2x2 blocks, or a small batch at any size) MIOpen picks split-K kernels whose
+            # float atomics make the features differ in the last bits from call to call (measured 2.5e-6), and the flow
+            # amplifies that.  Here split-K slices are added in a fixed order and the arithmetic is fp32-grade where the
+            # mode has one: the whole forward pass is bit-reproducible
+            # (tests/test_hip_modules.py::test_forward_pass_is_bit_reproducible).  RFN_VGG_CONV=miopen: the old route.
+            x = K.conv_ep(x.contiguous(), None, m.weight, None, None, 0, 0,
+                          prec="bf16x6" if K.CONV_PRECISION == "mixed" else None)
         else:
             x = m(x)
         i += 1
     return x
+
+
+def _own_conv(m, x):
+    return (isinstance(m, nn.Conv2d) and x.is_cuda and x.dtype == torch.float32
+            and tuple(m.kernel_size) == (3, 3) and tuple(m.stride) == (1, 1) and tuple(m.padding) == (1, 1)
+            and tuple(m.dilation) == (1, 1) and m.groups == 1 and m.bias is None
+            and os.environ.get("RFN_VGG_CONV", "own") != "miopen")
 
 
 class Squeeze2dDecoder(nn.Module):
@@ -390,7 +406,15 @@ class _StepConvAct(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, w, b, stash, slope):
-        y = F.conv2d(x, w, b, padding=1)
+        if x.is_cuda and x.dtype == torch.float32 and tuple(w.shape[2:]) == (3, 3):
+            # own convolution kernel (fixed summation order), not MIOpen: see run_time_batched
+            fp = K.fwd_prec(int(x.shape[2]), int(x.shape[3]))
+            wd = w.detach()
+            y = K.conv2d_raw(x.contiguous(), None, K.pack_weight(wd, prec=fp), int(w.shape[0]), 3,
+                             0 if b is None else 3, None if b is None else b.detach().reshape(-1).contiguous(), None, 0,
+                             prec=fp)
+        else:
+            y = F.conv2d(x, w, b, padding=1)
         if slope is not None:
             F.leaky_relu_(y, slope)
         ctx.stash, ctx.slope = stash, slope
@@ -546,7 +570,9 @@ class SimpleParamNet(nn.Module):
     def _recurrent_convs(self, force=False):
         """[(conv, leaky slope | None)] when the stack is [conv3x3 s1, no norm, leaky_relu]* + param_net, else None"""
         layers = list(self.net)
-        ok = torch.is_grad_enabled() and len(layers) % 3 == 0 and (self.param_net.weight.is_cuda or force)
+        # (also under no_grad: the forward-only loss -- bench parity check, evaluator -- must take the same launches as the
+        # training forward, not MIOpen's split-K kernels with their order-dependent float atomics)
+        ok = len(layers) % 3 == 0 and (self.param_net.weight.is_cuda or force)
         convs = []
         for i in range(0, len(layers), 3):
             if not ok:

@@ -27,6 +27,13 @@ void rfn_set_error(const char* fmt, ...);
         }                                                                     \
     } while (0)
 
+// Per-device scratch buffer of the split-K convolutions (grow-only, owned by the library, freed at process exit): the K
+// slices of a split convolution write their partial outputs here and a second kernel adds them in a fixed order -- no
+// order-dependent float atomics in any convolution.  Returns nullptr (error set) when the buffer would have to grow
+// while `s` is being captured into a hipGraph: run the same shapes eagerly once before capturing.  One buffer per device
+// serves all streams: split-K convolutions on different streams of a device must not overlap in time.
+float* rfn_workspace(hipStream_t s, size_t floats);
+
 // ---- wave / block reductions (sum) ---------------------------------------------------------------
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

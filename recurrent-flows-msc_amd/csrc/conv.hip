@@ -310,12 +310,14 @@ static int launch_conv(ConvParams& p, hipStream_t s) {
         if (ks_ > nchunks / 2) ks_ = nchunks / 2;
         if (ks_ > 1) {
             p.ksplit = ks_;
-            rfn_zero_f32(p.out1, (long)p.N * p.cout_split * HW, s);
-            if (p.cout_split != p.Cout) rfn_zero_f32(p.out2, (long)p.N * (p.Cout - p.cout_split) * HW, s);
+            p.ws_stride = (long)p.N * p.Cout * HW;
+            p.ws = rfn_workspace(s, (size_t)ks_ * (size_t)p.ws_stride);
+            if (!p.ws) return -8;
         }
     }
     grid.z = p.ksplit;
     hipLaunchKernelGGL(kern, grid, dim3(256), lds, s, p);
+    if (p.ksplit > 1) splitk_reduce(p, s);   // slices added in order: deterministic
     return 0;
 }
 

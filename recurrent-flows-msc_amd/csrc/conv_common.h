@@ -25,14 +25,37 @@ struct ConvParams {
     int TWp, TH, TF, tw_shift, th_shift;
     int n_wtiles, n_htiles, n_ftiles;
     int P2, P2_shift;  // (unused by the forward kernel; kept for layout compatibility)
-    int ksplit;        // gridDim.z: the K (input channel chunk) range is split over z, partial sums meet by atomicAdd
+    int ksplit;        // gridDim.z: the K (input channel chunk) range is split over z; slice z writes its partial outputs to
+                       // ws + z * ws_stride (out1's elements, then out2's, both dense) and splitk_reduce_kernel adds
+                       // the slices in order (deterministic: no float atomics)
     int w_lds_off;     // float offset of the weight tile inside dynamic LDS (16-byte aligned)
     // ep_mode 4 (data-gradient conv fused with the backward of the producer's ActNorm+activation epilogue):
     const float* ybuf;  // saved forward activation y = act((u+b)*exp(l)), same shape as the output
     long ybuf_ns;
     int npl;            // split-precision planes per operand: 0 / 2 = bf16x3, 3 = bf16x6 (generic tile kernel only)
     float* part;        // [2][Cout] sums Σ gu, Σ g*y, accumulated with float atomics (caller zeroes)
+    float* ws;          // split-K partial outputs (rfn_workspace), ksplit slices of ws_stride floats
+    long ws_stride;
 };
+
+// out[i] = sum_z ws[z * stride + i], z ascending (the second pass of a split-K convolution); n % 4 == 0 not required
+static __global__ void splitk_reduce_kernel(const float* __restrict__ ws, long stride, int ksplit, float* __restrict__ out1,
+                                            long n1, float* __restrict__ out2, long n2) {
+    const long n = n1 + n2;
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        float a = ws[i];
+        for (int z = 1; z < ksplit; ++z) a += ws[(long)z * stride + i];
+        if (i < n1) out1[i] = a;
+        else out2[i - n1] = a;
+    }
+}
+static inline void splitk_reduce(const ConvParams& p, hipStream_t s) {
+    const long HW = (long)p.H * p.W, n1 = (long)p.N * p.cout_split * HW, n2 = (long)p.N * (p.Cout - p.cout_split) * HW;
+    long blocks = (n1 + n2 + 255) / 256;
+    if (blocks > 2048) blocks = 2048;
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)blocks), dim3(256), 0, s, p.ws, p.ws_stride, p.ksplit, p.out1, n1,
+                       p.out2, n2);
+}
 
 // Epilogue shared by the fp32 and the bf16x3 kernels (the C/D register layout of the 32x32 MFMA tile does not depend
 // on the input dtype): per-channel affine + activation, bounds, output split over two tensors, accumulate / atomic.
@@ -116,9 +139,11 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
     }
     if (fast) {
         float* obase[TPX];
+        // (split-K: slice z stores into its own dense copy of out1 inside the workspace; out1 is dense then)
+        float* const o1 = (!FASTONLY && p.ksplit > 1) ? p.ws + (long)blockIdx.z * p.ws_stride : p.out1;
 #pragma unroll
         for (int t = 0; t < TPX; ++t)
-            obase[t] = p.out1 + pn[t] * p.out1_ns + (long)(co_base + 4 * kk) * HW + ppix[t];
+            obase[t] = o1 + pn[t] * p.out1_ns + (long)(co_base + 4 * kk) * HW + ppix[t];
 #pragma unroll
         for (int a = 0; a < TCO; ++a) {
 #pragma unroll
@@ -139,10 +164,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                     }
                     if (pvalid[t]) {
                         float* dst = obase[t] + (long)cidx * HW;
-                        if (FASTONLY) {
+                        if (FASTONLY || p.ksplit > 1) {
                             *dst = v;
-                        } else if (p.ksplit > 1) {
-                            atomicAdd(dst, v);
                         } else {
                             if (p.acc1) v += *dst;
                             *dst = v;
@@ -169,6 +192,8 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
             }
             const bool first = co < p.cout_split;
             float* obase = first ? p.out1 : p.out2;
+            if (p.ksplit > 1)   // slice z of the workspace: [out1 dense | out2 dense]
+                obase = p.ws + (long)blockIdx.z * p.ws_stride + (first ? 0 : (long)p.N * p.cout_split * HW);
             const long ons = first ? p.out1_ns : p.out2_ns;
             const int oc = first ? co : co - p.cout_split;
             const int accm = first ? p.acc1 : p.acc2;
@@ -183,7 +208,7 @@ __device__ __forceinline__ void conv_epilogue(const ConvParams& p, f32x16 (&acc)
                 }
                 float* dst = obase + pn[t] * ons + (long)oc * HW + ppix[t];
                 if (p.ksplit > 1) {
-                    atomicAdd(dst, v);
+                    *dst = v;
                 } else {
                     if (accm) v += *dst;
                     *dst = v;

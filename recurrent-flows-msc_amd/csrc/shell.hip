@@ -15,6 +15,38 @@ void rfn_set_error(const char* fmt, ...) {
 extern "C" const char* rfn_last_error(void) { return g_err; }
 extern "C" int rfn_abi_version(void) { return 1; }
 
+#include <map>
+#include <mutex>
+float* rfn_workspace(hipStream_t s, size_t floats) {
+    // ONE buffer per device, whatever the stream: a hipGraph is captured on a fresh stream of its own, which must find
+    // the buffer its eager warm-up runs (on other streams) have grown.  Consequence, stated in include/rfn_hip.h: split-K
+    // convolutions issued on DIFFERENT streams of one device must not overlap in time.
+    static std::mutex mu;
+    static std::map<int, std::pair<float*, size_t>> tab;
+    std::lock_guard<std::mutex> lock(mu);
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    auto& e = tab[dev];
+    if (e.second >= floats) return e.first;
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    if (hipStreamIsCapturing(s, &st) == hipSuccess && st != hipStreamCaptureStatusNone) {
+        rfn_set_error("split-K workspace must grow to %zu floats during a hipGraph capture: run this shape eagerly first", floats);
+        return nullptr;
+    }
+    if (e.first) (void)hipFree(e.first);   // (synchronises with the device: nothing in flight still uses it)
+    e.first = nullptr;
+    e.second = 0;
+    const size_t want = floats + floats / 4 + 1024;
+    float* ptr = nullptr;
+    if (hipMalloc(&ptr, want * sizeof(float)) != hipSuccess) {
+        rfn_set_error("split-K workspace: hipMalloc of %zu bytes failed", want * sizeof(float));
+        return nullptr;
+    }
+    e.first = ptr;
+    e.second = want;
+    return ptr;
+}
+
 // ------------------------------------------------------------------------------------------------ squeeze2d
 // forward: each thread reads one float2 (input row 2h+i, cols 2w,2w+1) and writes the two output planes j=0,1.
 __global__ void squeeze2d_fwd_kernel(const float* __restrict__ x, long x_ns, float* __restrict__ y, long y_ns, int N,
@@ -862,7 +894,8 @@ struct ShellFwdParams {
     float* o_out;
     const float* scale;
     const float* scale_shift;
-    float* logdet;  // [N], accumulated (atomicAdd)
+    float* logdet;  // this launch's log-det partials [n_blocks][LDS_] (LDS_ = ld_slots), WRITTEN: slot s of block b =
+                    // the block's sum for frame (b * PB) / HW + s; rfn_logdet_reduce_f32 adds them in a fixed order
     int clamp_type, tail;
     const float* bias;  // head: next step's ActNorm parameters and C x C matrix; znext = W ((v + bias) * exp(logs))
     const float* logs;
@@ -872,11 +905,12 @@ struct ShellFwdParams {
     int head;
     int N, C, H, W, PB;
     int ld_const;  // head: also add the step's parameter-only log-det term HW * sum_c logs[c] to logdet[n]
+    int ld_slots;  // frames a block can touch: (PB - 1) / HW + 2
 };
 
 __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParams q_) {
     extern __shared__ float lds[];  // head: [C][PB]
-    __shared__ float fr[66];        // per-frame log-det partials of the block (maps smaller than a wave)
+    __shared__ float red[256];      // log-det shares of the block's threads
     const ShellFwdParams& a = q_;
     const int PB = a.PB, C = a.C, Ch = C >> 1, HW = a.H * a.W;
     const int px = threadIdx.x & (PB - 1), ig = threadIdx.x / PB, NG = 256 / PB;
@@ -928,29 +962,39 @@ __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParam
         }
         if (a.head) lds[c * PB + px] = (v + a.bias[c]) * expf(a.logs[c]);
     }
-    if (a.tail) {
-        if ((HW & 63) == 0) {  // a wave's 64 pixels lie in one frame
-            const float tot = wave_sum(lsacc);
-            if ((threadIdx.x & 63) == 0 && valid) atomicAdd(&a.logdet[n], tot);
-        } else if (PB / HW + 2 <= 66) {
-            // small maps: a block spans a few frames; their sums meet in LDS and leave as ONE global atomic per frame
-            const int n0 = (int)(((long)blockIdx.x * PB) / HW);
-            for (int e = threadIdx.x; e < 66; e += 256) fr[e] = 0.f;
+    if (a.logdet) {
+        // log-det contribution of this block per frame, WITHOUT atomics (a forward pass must not depend on the order in
+        // which workgroups finish): every thread's share meets in LDS and is added per frame in a fixed order
+        float contrib = lsacc;
+        if (a.ld_const && a.head && valid && p == 0 && ig == 0) {  // once per frame: HW * sum_c logs[c]
+            float cs = 0.f;
+            for (int c = 0; c < C; ++c) cs += a.logs[c];
+            contrib += cs * (float)HW;
+        }
+        const int n0 = (int)(((long)blockIdx.x * PB) / HW);
+        float* out = a.logdet + (long)blockIdx.x * a.ld_slots;
+        if ((long)n0 * HW <= (long)blockIdx.x * PB && ((long)blockIdx.x * PB + PB) <= (long)(n0 + 1) * HW) {
+            // the whole block lies inside frame n0 (the shallow levels): butterfly per wave, four waves in order
+            const float tot = wave_sum(contrib);
+            if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
             __syncthreads();
-            if (valid) atomicAdd(&fr[n - n0], lsacc);
+            if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
+            if (threadIdx.x > 0 && threadIdx.x < a.ld_slots) out[threadIdx.x] = 0.f;
+        } else {
+            red[threadIdx.x] = valid ? contrib : 0.f;
             __syncthreads();
-            if (threadIdx.x < 66 && n0 + (int)threadIdx.x < a.N && fr[threadIdx.x] != 0.f)
-                atomicAdd(&a.logdet[n0 + threadIdx.x], fr[threadIdx.x]);
-        } else if (valid && lsacc != 0.f) {
-            atomicAdd(&a.logdet[n], lsacc);
+            if (threadIdx.x < a.ld_slots) {   // slot s: frame n0 + s; its threads are the pixels px with that frame
+                const int fs = n0 + threadIdx.x;
+                float tot = 0.f;
+                for (int t = 0; t < 256; ++t) {
+                    const long qq = (long)blockIdx.x * PB + (t & (PB - 1));
+                    if ((int)(qq / HW) == fs) tot += red[t];
+                }
+                out[threadIdx.x] = tot;
+            }
         }
     }
     if (!a.head) return;
-    if (a.ld_const && valid && p == 0 && ig == 0) {  // once per frame
-        float cs = 0.f;
-        for (int c = 0; c < C; ++c) cs += a.logs[c];
-        atomicAdd(&a.logdet[n], cs * (float)HW);
-    }
     __syncthreads();
     if (valid) {
         float* dst = a.znext + n * a.znext_ns + p;
@@ -962,6 +1006,47 @@ __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParam
             dst[(long)i * HW] = acc;
         }
     }
+}
+
+// pixels per block of glow_shell_fwd_kernel for N frames of HW pixels and C channels (also fixes the layout of its log-det
+// partials: rfn_glow_shell_fwd_ld_floats)
+static int shell_fwd_pb(int N, int C, int HW) {
+    int PB = shell_pb(C);
+    const long tot = (long)N * HW;
+    while (PB > 32 && tot / PB < 256) PB >>= 1;
+    return PB;
+}
+/* floats of ONE launch's log-det partials ([blocks][slots]) */
+extern "C" long rfn_glow_shell_fwd_ld_floats(int N, int C, int H, int W) {
+    if (N <= 0 || C <= 0 || H <= 0 || W <= 0) return 0;
+    const int HW = H * W, PB = shell_fwd_pb(N, C, HW);
+    return (((long)N * HW + PB - 1) / PB) * ((PB - 1) / HW + 2);
+}
+// logdet[n] (+)= sum over launches k (ascending) and over the blocks b that touch frame n (ascending) of part[k][b][n - n0(b)]
+__global__ __launch_bounds__(256) void logdet_reduce_kernel(const float* __restrict__ part, long per_launch, int n_launch,
+                                                            int N, int HW, int PB, int slots, float* __restrict__ logdet,
+                                                            int accumulate) {
+    const int n = blockIdx.x * 256 + threadIdx.x;
+    if (n >= N) return;
+    const long b_lo = ((long)n * HW) / PB, b_hi = ((long)(n + 1) * HW - 1) / PB;
+    float acc = accumulate ? logdet[n] : 0.f;
+    for (int k = 0; k < n_launch; ++k) {
+        const float* pk = part + (long)k * per_launch;
+        for (long b = b_lo; b <= b_hi; ++b) acc += pk[b * slots + (n - (int)((b * PB) / HW))];
+    }
+    logdet[n] = acc;
+}
+/* second pass of the level's log-det: part = n_launch consecutive partial buffers of rfn_glow_shell_fwd_f32 (each
+ * rfn_glow_shell_fwd_ld_floats(N, C, H, W) floats) -> logdet [N], written (accumulate = 0) or added to */
+extern "C" int rfn_logdet_reduce_f32(const float* part, int n_launch, float* logdet, int accumulate, int N, int C, int H,
+                                     int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(part && logdet && n_launch >= 1 && N >= 0 && C > 0 && H > 0 && W > 0, -1);
+    if (N == 0) return 0;
+    const int HW = H * W, PB = shell_fwd_pb(N, C, HW);
+    hipLaunchKernelGGL(logdet_reduce_kernel, dim3((N + 255) / 256), dim3(256), 0, (hipStream_t)stream, part,
+                       rfn_glow_shell_fwd_ld_floats(N, C, H, W), n_launch, N, HW, PB, (PB - 1) / HW + 2, logdet, accumulate);
+    RFN_LAUNCH_CHECK();
+    return 0;
 }
 
 extern "C" int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const float* o_in, long o_ns,
@@ -978,10 +1063,8 @@ extern "C" int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const
     RFN_CHECK_ARG(!ld_const || (head && logdet), -7);
     if (N == 0) return 0;
     const int HW = H * W;
-    int PB = shell_pb(C);
-    long tot = (long)N * HW;
-    while (PB > 32 && tot / PB < 256) PB >>= 1;
-    if (tail && PB < 64 && (HW & 63) == 0) PB = 64;  // the wave-level log-det reduction needs whole waves per pixel run
+    const int PB = shell_fwd_pb(N, C, HW);
+    const long tot = (long)N * HW;
     size_t lds = head ? (size_t)C * PB * 4 : 0;
     if (lds > 160 * 1024) {
         rfn_set_error("glow_shell_fwd: C=%d too large for the LDS-staged kernel", C);
@@ -991,7 +1074,7 @@ extern "C" int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const
         (void)hipFuncSetAttribute((const void*)glow_shell_fwd_kernel, hipFuncAttributeMaxDynamicSharedMemorySize,
                                   (int)lds);
     ShellFwdParams a = {z, z_ns, P, o_in, o_ns, b3, l3, o_out, scale, scale_shift, logdet, clamp_type, tail,
-                        bias, logs, Wm, znext, znext_ns, head, N, C, H, W, PB, ld_const};
+                        bias, logs, Wm, znext, znext_ns, head, N, C, H, W, PB, ld_const, (PB - 1) / HW + 2};
     hipLaunchKernelGGL(glow_shell_fwd_kernel, dim3((unsigned)((tot + PB - 1) / PB)), dim3(256), lds, (hipStream_t)stream,
                        a);
     RFN_LAUNCH_CHECK();
@@ -1695,7 +1778,7 @@ extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const floa
 // Flow/glow_modules.py:178-207 for the K steps of a flow level in one launch each way (the reference -- and a torch
 // restatement -- spends ~17 launches per level forward and ~20 backward on this C x C algebra):
 //   Lm = lower o tril(-1) + I,   Um = upper o triu(+1) + diag(sign_s * exp(log_s)),   W = P Lm Um,
-//   dlogdet = HW * sum(log_s)  (summed over the K steps into ONE scalar with float atomics: the caller zeroes it).
+//   dlogdet = HW * sum(log_s)  (summed over the K steps, in step order, into ONE scalar that is WRITTEN: no atomics).
 // Backward, given gW and the gradient gc of the scalar:  gT = P^T gW;  g_lower = (gT Um^T) o tril(-1);
 //   g_upper = (Lm^T gT) o triu(+1);  g_log_s = diag(Lm^T gT) * sign_s * exp(log_s) + gc * HW.
 // One workgroup per step, the three matrices in LDS (C <= RFN_INVCONV_MAX_CHANNELS).  Parameters arrive as pointer arrays in the kernel
@@ -1707,7 +1790,7 @@ struct InvConvWeightsParams {
     const float* log_s[RFN_INVCONV_MAX_STEPS];
     const float* sign_s[RFN_INVCONV_MAX_STEPS];
     float* W;            // [K][C][C]
-    float* logdet;       // scalar, accumulated
+    float* logdet;       // scalar, written
     const float* gW;     // backward: [K][C][C]
     const float* gc;     // backward: gradient of the scalar (may be null)
     float* g_lower;      // [K][C][C]
@@ -1777,11 +1860,14 @@ __global__ __launch_bounds__(256) void invconv_weights_fwd_kernel(const InvConvW
     __syncthreads();
     float* W = q.W + (long)k * C * C;
     invconv_mm<false, false>(B0, B2, C, [&](int r, int c, float v) { W[r * C + c] = v; });  // W = P T
-    if (threadIdx.x < 64) {  // one wave: HW * sum(log_s)
-        float v = 0.f;
-        for (int c = threadIdx.x; c < C; c += 64) v += q.log_s[k][c];
-        v = wave_sum(v);
-        if (threadIdx.x == 0) atomicAdd(q.logdet, v * q.hw);
+    if (k == 0 && threadIdx.x < 64) {  // one wave of ONE block: HW * sum over the steps (in order) of sum(log_s): no atomics
+        float tot = 0.f;
+        for (int kk = 0; kk < (int)gridDim.x; ++kk) {
+            float v = 0.f;
+            for (int c = threadIdx.x; c < C; c += 64) v += q.log_s[kk][c];
+            tot += wave_sum(v) * q.hw;
+        }
+        if (threadIdx.x == 0) *q.logdet = tot;
     }
 }
 __global__ __launch_bounds__(256) void invconv_weights_bwd_kernel(const InvConvWeightsParams q) {

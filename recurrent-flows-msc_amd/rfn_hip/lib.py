@@ -64,6 +64,8 @@ SIGNATURES = {
     "rfn_coupling_po_pack": [_c_f, _c_i, _c_s],
     "rfn_coupling_po_fwd": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_l,
                             _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_glow_shell_fwd_ld_floats": [_c_i, _c_i, _c_i, _c_i],
+    "rfn_logdet_reduce_f32": [_c_f, _c_i, _c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_s],
     "rfn_coupling_po_mask_floats": [_c_i, _c_i, _c_i],
     "rfn_coupling_po_bwd_supported": [_c_i, _c_i, _c_i, _c_i],
     "rfn_coupling_po_bwd_packed_bytes": [_c_i],
@@ -119,7 +121,7 @@ SIGNATURES = {
 _RESTYPES = {"rfn_last_error": ctypes.c_char_p, "rfn_stepbn_scratch_floats": ctypes.c_long, "rfn_packed_weight_size": ctypes.c_long,
              "rfn_packed_weight_size_bf16x3": ctypes.c_long, "rfn_packed_weight_size_bf16x6": ctypes.c_long,
              "rfn_smallmap_packed_size": ctypes.c_long,
-             "rfn_coupling_po_packed_bytes": ctypes.c_long, "rfn_coupling_po_mask_floats": ctypes.c_long,
+             "rfn_coupling_po_packed_bytes": ctypes.c_long, "rfn_coupling_po_mask_floats": ctypes.c_long, "rfn_glow_shell_fwd_ld_floats": ctypes.c_long,
              "rfn_coupling_po_bwd_packed_bytes": ctypes.c_long, "rfn_coupling_po_bwd_part_floats": ctypes.c_long}
 
 _lib = None

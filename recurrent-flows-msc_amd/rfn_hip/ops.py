@@ -685,11 +685,11 @@ class ConvFn(torch.autograd.Function):
     p0/p1: ep_mode 1 -> (actnorm bias, actnorm logs); 2 -> (conv bias, logs); 3 -> (conv bias, None)."""
 
     @staticmethod
-    def forward(ctx, in1, in2, w, p0, p1, ep_mode, act):
+    def forward(ctx, in1, in2, w, p0, p1, ep_mode, act, prec=None):
         Cout, ks = int(w.shape[0]), int(w.shape[2])
         p0f = None if p0 is None else p0.detach().reshape(-1).contiguous()
         p1f = None if p1 is None else p1.detach().reshape(-1).contiguous()
-        fp = fwd_prec(int(in1.shape[2]), int(in1.shape[3]))
+        fp = prec if prec is not None else fwd_prec(int(in1.shape[2]), int(in1.shape[3]))
         y = conv2d_raw(in1, in2, pack_weight(w, prec=fp), Cout, ks, ep_mode, p0f, p1f, act, prec=fp)
         ctx.save_for_backward(in1, in2, w, p1f, y)
         ctx.cfg = (ep_mode, act, None if p0 is None else p0.shape, None if p1 is None else p1.shape)
@@ -718,11 +718,12 @@ class ConvFn(torch.autograd.Function):
             conv2d_raw(gy, None, wt, Cin, ks, 0, None, None, 0, out1=g1, out2=g2, cout_split=C1)
         if ctx.needs_input_grad[2]:
             gw = conv2d_wgrad(in1, in2, gy, Cout, ks)
-        return g1, g2, gw, gp0, gp1, None, None
+        return g1, g2, gw, gp0, gp1, None, None, None
 
 
-def conv_ep(in1, in2, w, p0, p1, ep_mode, act):
-    return ConvFn.apply(in1, in2, w, p0, p1, ep_mode, act)
+def conv_ep(in1, in2, w, p0, p1, ep_mode, act, prec=None):
+    """`prec` (optional): forward arithmetic ('bf16x3' | 'bf16x6' | 'f32') instead of this map size's default"""
+    return ConvFn.apply(in1, in2, w, p0, p1, ep_mode, act, prec)
 
 
 def _f(t):
@@ -971,12 +972,16 @@ class GlowLevelFn(torch.autograd.Function):
                for k in range(Kn)]
         want_masks = any(ctx.needs_input_grad)
         Wd = Wst.detach().contiguous()
-        dl = torch.zeros(N, device=x.device, dtype=torch.float32)
+        # log-det: every shell launch WRITES its per-block partial sums into its own slice; one reduce launch adds them
+        # per frame in a fixed order (no float atomics anywhere in the forward pass: bit-reproducible)
+        ldf = int(L.load().rfn_glow_shell_fwd_ld_floats(N, C, H, W))
+        ldp = torch.empty((Kn + 1, ldf), device=x.device, dtype=torch.float32)
+        dl = torch.empty(N, device=x.device, dtype=torch.float32)
         xp, xns = L.frames(x, "x")
         z = torch.empty_like(x)
         zp, zns = L.frames(z, "z")
         ab0, al0 = _f(prm[0][0]), _f(prm[0][1])
-        L.call("rfn_glow_shell_fwd_f32", xp, _l(xns), None, None, _l(0), None, None, None, None, None, L.dev(dl), _i(0),
+        L.call("rfn_glow_shell_fwd_f32", xp, _l(xns), None, None, _l(0), None, None, None, None, None, L.dev(ldp[0]), _i(0),
                L.dev(ab0), L.dev(al0), L.dev(Wd[0]), zp, _l(zns), _i(1), _i(N), _i(C), _i(H), _i(W),
                meta=_shell("glow_shell_fwd", x, 2))
         outs, h1s, h2s, os_, mks = [], [], [], [], []
@@ -997,7 +1002,7 @@ class GlowLevelFn(torch.autograd.Function):
                 op, ons = L.frames(o, "o")
                 args = (None, op, _l(ons), None, None, None)
                 nt = 2 + (0 if last else 1.5)
-            L.call("rfn_glow_shell_fwd_f32", zp, _l(zns), *args, L.dev(hold[2]), L.dev(hold[3]), L.dev(dl),
+            L.call("rfn_glow_shell_fwd_f32", zp, _l(zns), *args, L.dev(hold[2]), L.dev(hold[3]), L.dev(ldp[k + 1]),
                    _i(clamp_type), L.dev(hold[4]), L.dev(hold[5]), None if last else L.dev(Wd[k + 1]), znp, _l(znns),
                    _i(0 if last else 1), _i(N), _i(C), _i(H), _i(W), meta=_shell("glow_shell_fwd", z, nt))
             outs.append(z)
@@ -1005,6 +1010,8 @@ class GlowLevelFn(torch.autograd.Function):
             h2s.append(h2)
             os_.append(o)
             z = zn
+        L.call("rfn_logdet_reduce_f32", L.dev(ldp), _i(Kn + 1), L.dev(dl), _i(0), _i(N), _i(C), _i(H), _i(W),
+               meta=_shell("logdet_reduce", ldp, 1))
         has_masks = all(m is not None for m in mks)
         ctx.save_for_backward(x, cond, Wst, *flat, *outs, *h1s, *h2s, *os_,
                               *([m[0] for m in mks] + [m[1] for m in mks] if has_masks else []))
@@ -1324,7 +1331,7 @@ class InvConvWeightsFn(torch.autograd.Function):
         C = int(Lw[0].shape[0])
         arrs = InvConvWeightsFn._pointers(P, S, Lw, U, LS)
         W = torch.empty((Kn, C, C), device=Lw[0].device, dtype=torch.float32)
-        c = torch.zeros((), device=Lw[0].device, dtype=torch.float32)
+        c = torch.empty((), device=Lw[0].device, dtype=torch.float32)   # written by the kernel
         L.call("rfn_invconv_weights_fwd_f32", *arrs, L.dev(W), L.dev(c), _i(Kn), _i(C), _i(int(hw)),
                meta=_shell("invconv_weights_fwd", W, 4))
         ctx.cfg = (int(hw), Kn, C)
