@@ -400,7 +400,16 @@ int rfn_stepbn_fwd_f32(const float* x, const float* gamma, const float* beta, fl
                        rfn_stream_t stream);
 int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const float* beta, const float* g, const float* mean,
                        const float* var, float* sums, float* gx, float* ggamma, float* gbeta, int S, int B, int C, int HW,
-                       float eps, int act, float slope, rfn_stream_t stream);
+                       float eps, int act, float slope, int stage, int world, rfn_stream_t stream);
+/* Synchronised BatchNorm over `world` data-parallel ranks (same mathematics as one process on the
+ * global batch): forward = rfn_stepbn_fwd_f32 for the local moments, the caller combines the ranks' moments, then
+ * rfn_stepbn_apply_f32 normalises with the GIVEN statistics; backward = rfn_stepbn_bwd_f32 with stage 1 (partial sums
+ * only), the caller adds `sums` over the ranks, then stage 2 (apply; gx uses the global means of g' and g'*xhat, the
+ * parameter gradients are the sums divided by `world`: the reducer's rank average then gives the global-batch gradient).
+ * stage 0 / world 1 = the single-process behaviour. */
+int rfn_stepbn_apply_f32(const float* x, const float* gamma, const float* beta, float* y, const float* mean,
+                         const float* var, int S, int B, int C, int HW, float eps, int act, float slope,
+                         rfn_stream_t stream);
 
 /* ---- a9  ConvLSTMLayer.forward gate update  (Utils/modules.py:370-377): cc = conv output [N,4*Hc,HW] in gate order
  * i,f,o,g;  i=σ(cc_i+Wci∘c) f=σ(cc_f+Wcf∘c) g=tanh(cc_g) c'=f∘c+i∘g o=σ(cc_o+Wco∘c') h'=o∘tanh(c').

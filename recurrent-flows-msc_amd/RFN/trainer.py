@@ -168,6 +168,9 @@ class Solver(object):
         if not torch.cuda.is_available():
             return False
         import rfn_hip
+        if rdist.sync_batchnorm_on():
+            self._graph_error = "synchronised BatchNorm issues a collective per layer: eager launches only"
+            return False
         if not rfn_hip.graph_capture_safe():
             # see rfn_hip/__init__.py: replays are not trustworthy with packet capture on (memset nodes race), and the
             # flag only counts when it was in the environment before the HIP runtime initialised

@@ -151,8 +151,9 @@ def run_time_batched(seq, x, steps):
             # amplifies that.  Here split-K slices are added in a fixed order and the arithmetic is fp32-grade where the
             # mode has one: the whole forward pass is bit-reproducible
             # (tests/test_hip_modules.py::test_forward_pass_is_bit_reproducible).  RFN_VGG_CONV=miopen: the old route.
+            # (these layers were fp32 on MIOpen: fp32-grade here too, also in the all-bf16x3 test arithmetic)
             x = K.conv_ep(x.contiguous(), None, m.weight, None, None, 0, 0,
-                          prec="bf16x6" if K.CONV_PRECISION == "mixed" else None)
+                          prec="f32" if K.CONV_PRECISION == "f32" else "bf16x6")
         else:
             x = m(x)
         i += 1

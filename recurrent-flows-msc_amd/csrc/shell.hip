@@ -1532,6 +1532,7 @@ struct StepBnFused {
 };
 __device__ __forceinline__ void stepbn_moments(const float* __restrict__ x, const float* __restrict__ acc, int sc, int s,
                                                int c, int B, int C, int HW, int ny, int SC, float& m, float& v) {
+    if (!acc) return;   // statistics given by the caller (m, v preloaded): synchronised BatchNorm
     const float K = x[((long)s * B * C + c) * HW];
     const float n = (float)B * HW;
     float s1 = 0.f, s2 = 0.f;
@@ -1551,6 +1552,7 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
     const int SC = f.S * C;
     const unsigned nblk = gridDim.x - 1, bid = blockIdx.x - 1;
     if (blockIdx.x == 0) {
+        if (!f.acc) return;   // given statistics: nothing to finalise
         for (int sc = threadIdx.x; sc < SC; sc += blockDim.x) {
             float m, v;
             stepbn_moments(x, f.acc, sc, sc / C, sc % C, B, C, HW, f.ny, SC, m, v);
@@ -1580,7 +1582,7 @@ __global__ void stepbn_apply_kernel(const float* __restrict__ x, const float* __
         const unsigned r = idx / (unsigned)HW;  // frame * C + c
         const int c = (int)(r % (unsigned)C);
         const int s = (int)(r / (unsigned)C / (unsigned)B);
-        float m, vr;
+        float m = f.acc ? 0.f : f.mean_out[s * C + c], vr = f.acc ? 0.f : f.var_out[s * C + c];
         stepbn_moments(x, f.acc, s * C + c, s, c, B, C, HW, f.ny, SC, m, vr);
         const float rstd = rsqrtf(vr + eps);
         const float ga = gamma ? gamma[c] : 1.f, be = gamma ? beta[c] : 0.f;
@@ -1654,7 +1656,8 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
                                         const float* __restrict__ var, const float* __restrict__ gamma,
                                         const float* __restrict__ sg, const float* __restrict__ sgx,
                                         float* __restrict__ gx, unsigned total, int B, int C, int HW, float eps, int act,
-                                        float slope, float* __restrict__ ggamma, float* __restrict__ gbeta, int S, int ny) {
+                                        float slope, float* __restrict__ ggamma, float* __restrict__ gbeta, int S, int ny,
+                                        int world) {
     // (one extra workgroup, the first, for the parameter gradients = the per-step sums added over the steps)
     const int SC = S * C;
     const unsigned nblk = ggamma ? gridDim.x - 1 : gridDim.x, bid = ggamma ? blockIdx.x - 1 : blockIdx.x;
@@ -1665,12 +1668,14 @@ __global__ void stepbn_bwd_apply_kernel(const float* __restrict__ x, const float
                 a += sgx[(long)i * C + c];
                 b += sg[(long)i * C + c];
             }
-            ggamma[c] = a;
-            gbeta[c] = b;
+            // (world > 1: the partial sums were added over the ranks for gx; a parameter gradient is this rank's
+            // share of a rank average, so the sum over ranks is divided by their number)
+            ggamma[c] = a / (float)world;
+            gbeta[c] = b / (float)world;
         }
         return;
     }
-    const float inv_n = 1.f / (float)(B * HW);
+    const float inv_n = 1.f / ((float)(B * HW) * (float)world);
     const unsigned nvec = total / VEC;
     for (unsigned iv = bid * blockDim.x + threadIdx.x; iv < nvec; iv += nblk * blockDim.x) {
         const unsigned idx = iv * VEC;
@@ -1744,13 +1749,41 @@ extern "C" int rfn_stepbn_fwd_f32(const float* x, const float* gamma, const floa
     RFN_LAUNCH_CHECK();
     return 0;
 }
+/* normalise + activate with GIVEN per-step statistics mean / var [S*C] (synchronised BatchNorm across data-parallel
+ * ranks: the caller combined the ranks' moments); one launch */
+extern "C" int rfn_stepbn_apply_f32(const float* x, const float* gamma, const float* beta, float* y, const float* mean,
+                                    const float* var, int S, int B, int C, int HW, float eps, int act, float slope,
+                                    rfn_stream_t stream) {
+    RFN_CHECK_ARG(x && y && mean && var && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    RFN_CHECK_ARG((gamma && beta) || (!gamma && !beta), -2);
+    const long total = (long)S * B * C * HW;
+    RFN_CHECK_ARG(total < (1L << 31), -3);
+    StepBnFused f;
+    memset(&f, 0, sizeof(f));
+    f.mean_out = const_cast<float*>(mean); f.var_out = const_cast<float*>(var); f.S = S;
+    const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0;
+    const long nthr = v4 ? total / 4 : total;
+    const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
+    if (v4)
+        hipLaunchKernelGGL(stepbn_apply_kernel<4>, dim3(grid + 1), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                           (unsigned)total, B, C, HW, eps, act, slope, f);
+    else
+        hipLaunchKernelGGL(stepbn_apply_kernel<1>, dim3(grid + 1), dim3(256), 0, (hipStream_t)stream, x, gamma, beta, y,
+                           (unsigned)total, B, C, HW, eps, act, slope, f);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
 // the whole backward of one layer in TWO launches (per-step partial sums, apply): sums = scratch
 // [rfn_stepbn_scratch_floats] (sg | sgx); ggamma / gbeta [C] (both or neither) = the parameter gradients, written by the
 // apply kernel
 extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const float* beta, const float* g, const float* mean,
                                   const float* var, float* sums, float* gx, float* ggamma, float* gbeta, int S, int B,
-                                  int C, int HW, float eps, int act, float slope, rfn_stream_t stream) {
+                                  int C, int HW, float eps, int act, float slope, int stage, int world,
+                                  rfn_stream_t stream) {
+    // stage 0: both launches; 1: the partial sums only; 2: the apply only (the caller has added `sums` over `world`
+    // data-parallel ranks in between: synchronised BatchNorm; mean / var are the global statistics)
     RFN_CHECK_ARG(x && g && mean && var && sums && gx && S > 0 && B > 0 && C > 0 && HW > 0, -1);
+    RFN_CHECK_ARG(stage >= 0 && stage <= 2 && world >= 1, -4);
     RFN_CHECK_ARG(((gamma && beta) || (!gamma && !beta)) && ((ggamma && gbeta) || (!ggamma && !gbeta)), -2);
     const long total = (long)S * B * C * HW;
     RFN_CHECK_ARG(total < (1L << 31), -3);
@@ -1758,18 +1791,23 @@ extern "C" int rfn_stepbn_bwd_f32(const float* x, const float* gamma, const floa
     const int ny = stepbn_split(S, B, C);
     float* sg = sums;
     float* sgx = sums + (long)ny * S * C;
-    hipLaunchKernelGGL(stepbn_bwd_reduce_kernel, dim3(S * C, ny), dim3(256), 0, st, x, gamma, beta, g, mean, var, sg, sgx, B,
-                       C, HW, eps, act, slope);
+    if (stage != 2)
+        hipLaunchKernelGGL(stepbn_bwd_reduce_kernel, dim3(S * C, ny), dim3(256), 0, st, x, gamma, beta, g, mean, var, sg, sgx,
+                           B, C, HW, eps, act, slope);
+    if (stage == 1) {
+        RFN_LAUNCH_CHECK();
+        return 0;
+    }
     const bool v4 = HW % 4 == 0 && (((uintptr_t)x | (uintptr_t)g | (uintptr_t)gx) & 15) == 0;
     const long nthr = v4 ? total / 4 : total;
     const int grid = (int)((nthr + 255) / 256 < 16384 ? (nthr + 255) / 256 : 16384);
     const int extra = ggamma ? 1 : 0;
     if (v4)
         hipLaunchKernelGGL(stepbn_bwd_apply_kernel<4>, dim3(grid + extra), dim3(256), 0, st, x, beta, g, mean, var, gamma,
-                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S, ny);
+                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S, ny, world);
     else
         hipLaunchKernelGGL(stepbn_bwd_apply_kernel<1>, dim3(grid + extra), dim3(256), 0, st, x, beta, g, mean, var, gamma,
-                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S, ny);
+                           sg, sgx, gx, (unsigned)total, B, C, HW, eps, act, slope, ggamma, gbeta, S, ny, world);
     RFN_LAUNCH_CHECK();
     return 0;
 }

@@ -334,6 +334,10 @@ extern "C" int rfn_gemm_wgrad_grouped_bf16x3(const float* const* a, long a_ns, i
 static void select_wgrad_implicit(GemmWgradParams& p, hipStream_t s) {
     if (p.M > 128 && p.total >= 100000)
         launch_gemm_wgrad<4, 2, 2, 3, 64, 1>(p, s);   // 256 x 192, 8 waves
+    else if (p.M <= 32 && p.G == 0)
+        // few output channels (the 16- / 32-channel blocks of the extractor / upscaler on 64x64 and 32x32 maps): one 32-row
+        // tile instead of 128 rows of which 16 are real (the clamped rows were 8x the loads and MFMAs of the gradient)
+        launch_gemm_wgrad<1, 4, 1, 2, 32, 1>(p, s);   // 32 x 256
     else
         launch_gemm_wgrad<2, 2, 2, 2, 64, 1>(p, s);   // 128 x 128
 }

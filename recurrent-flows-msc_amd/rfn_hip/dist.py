@@ -265,3 +265,42 @@ def shard_optimizer_state(state_dict, module, group=None, sharded_names=SHARDED_
     out = dict(state_dict)
     out["state"] = state
     return out
+
+
+# ---- synchronised BatchNorm (SURVEY 8e item 2) --------------------------------------------------------------------
+# Off by default: the bench replays a captured hipGraph per rank and a collective per BatchNorm layer (2 x 20 per step)
+# cannot live inside it; with local statistics the data-parallel run is a documented deviation from "one process on the
+# global batch".  RFN_SYNC_BN=1 (or set_sync_batchnorm(True)) makes every per-step BatchNorm of the extractor / upscaler
+# use the global batch's statistics: eager launches only (Solver.capture_graph refuses), exact parity with a single
+# process (tests/test_hip_modules.py::test_data_parallel_rfn_equals_single_process_global_batch).
+_SYNC_BN = None
+
+
+def set_sync_batchnorm(on):
+    global _SYNC_BN
+    _SYNC_BN = bool(on)
+
+
+def sync_batchnorm_on():
+    import os
+    on = _SYNC_BN if _SYNC_BN is not None else os.environ.get("RFN_SYNC_BN") == "1"
+    return bool(on) and is_dist()
+
+
+def all_gather_cat(t, group=None):
+    """[1, ...] per rank -> [world, ...] (rank order), through the group's device"""
+    dev = collective_device(group)
+    src = t.detach().to(dev).contiguous()
+    if src.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream().synchronize()
+    parts = [torch.empty_like(src) for _ in range(dist.get_world_size(group))]
+    dist.all_gather(parts, src, group=group)
+    return torch.cat(parts, 0).to(t.device)
+
+
+def all_reduce_sum_(t, group=None):
+    """in-place sum over ranks of a device tensor"""
+    if t.is_cuda and dist.get_backend(group) == "gloo":
+        torch.cuda.current_stream().synchronize()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
+    return t

@@ -109,7 +109,9 @@ SIGNATURES = {
     "rfn_stepbn_fwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, ctypes.c_float, ctypes.c_void_p,
                            _c_i, _c_i, _c_i, _c_i, ctypes.c_float, _c_i, ctypes.c_float, _c_s],
     "rfn_stepbn_bwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float,
-                           _c_i, ctypes.c_float, _c_s],
+                           _c_i, ctypes.c_float, _c_i, _c_i, _c_s],
+    "rfn_stepbn_apply_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_i, ctypes.c_float, _c_i, ctypes.c_float,
+                             _c_s],
     "rfn_adam_chunk_elems": [],
     "rfn_adam_step_f32": [ctypes.c_void_p, ctypes.c_void_p, _c_i, ctypes.c_double, ctypes.c_double, ctypes.c_double,
                           ctypes.c_double, ctypes.c_double, _c_i, _c_s],

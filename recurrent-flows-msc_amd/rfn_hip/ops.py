@@ -446,7 +446,7 @@ def conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena=None):
         big = Cout > 128 and N * H * W >= 100000
         L.call("rfn_conv3x3_wgrad_implicit_bf16x3", gp, _l(gns), _i(Cout), i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2),
                L.dev(gw), _i(N), _i(H), _i(W),
-               meta=("wgrad", "gemm_wgrad_b3_kernel<%s,1>" % ("4,2,2,3,64" if big else "2,2,2,2,64"),
+               meta=("wgrad", "gemm_wgrad_b3_kernel<%s,1>" % ("4,2,2,3,64" if big else ("1,4,1,2,32" if Cout <= 32 else "2,2,2,2,64")),
                      2.0 * N * H * W * Cout * 9 * Cin, "F%d %dx%d HW%d implicit3x3" % (N, Cout, 9 * Cin, H * W),
                      4.0 * (N * H * W * (Cout + Cin) + Cout * 9 * Cin)))
         return gw.view(Cout, Cin, 3, 3)  # rows of the implicit operand are (ci, tap): already the torch layout
@@ -1538,6 +1538,10 @@ class StepBatchNormActFn(torch.autograd.Function):
     def forward(ctx, x, gamma, beta, S, eps, act, slope, running=None):
         ctx.set_materialize_grads(False)  # mean / var are not differentiable: no zero gradients built for them
         x = x.contiguous()
+        from . import dist as rdist
+        if rdist.sync_batchnorm_on():
+            return StepBatchNormActFn._forward_sync(ctx, x, gamma, beta, S, eps, act, slope, running)
+        ctx.world = 1
         SB, C, H, W = (int(v) for v in x.shape)
         B, HW = SB // S, H * W
         mean = torch.empty((S, C), device=x.device, dtype=torch.float32)
@@ -1563,6 +1567,45 @@ class StepBatchNormActFn(torch.autograd.Function):
         return y, mean, var
 
     @staticmethod
+    def _forward_sync(ctx, x, gamma, beta, S, eps, act, slope, running):
+        """synchronised BatchNorm (rfn_hip.dist.sync_batchnorm_on): the statistics of every step are those of the GLOBAL
+        batch -- local moments, one all-gather of [2, S, C] floats, equal-count combination, apply with the given
+        statistics; the running statistics follow the global moments (torch ops on [C] vectors)."""
+        import torch.distributed as dist
+        from . import dist as rdist
+        SB, C, H, W = (int(v) for v in x.shape)
+        B, HW = SB // S, H * W
+        world = dist.get_world_size()
+        mean = torch.empty((S, C), device=x.device, dtype=torch.float32)
+        var = torch.empty((S, C), device=x.device, dtype=torch.float32)
+        y = torch.empty_like(x)
+        gm = None if gamma is None else gamma.detach().contiguous()
+        bt = None if beta is None else beta.detach().contiguous()
+        nscr = int(L.load().rfn_stepbn_scratch_floats(S, B, C))
+        acc = torch.empty((nscr,), device=x.device, dtype=torch.float32)
+        L.call("rfn_stepbn_fwd_f32", L.dev(x), L.dev(gm), L.dev(bt), L.dev(y), L.dev(mean), L.dev(var), L.dev(acc),
+               None, None, None, None, ctypes.c_float(1.0), None, _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps),
+               _i(act), ctypes.c_float(slope))
+        st = rdist.all_gather_cat(torch.stack((mean, var)).unsqueeze(0))          # [world, 2, S, C]
+        mean = st[:, 0].mean(0).contiguous()
+        var = (st[:, 1].mean(0) + (st[:, 0] - mean).pow(2).mean(0)).contiguous()  # equal counts per rank
+        L.call("rfn_stepbn_apply_f32", L.dev(x), L.dev(gm), L.dev(bt), L.dev(y), L.dev(mean), L.dev(var), _i(S), _i(B),
+               _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
+        if running is not None:
+            rm, rv, cf, cfu, decay, nbt = running
+            n = B * HW * world
+            cfu_g = cf * (n / max(n - 1, 1))          # unbiased variance of the global batch
+            rm.mul_(decay).add_((cf.view(-1, 1) * mean).sum(0))
+            rv.mul_(decay).add_((cfu_g.view(-1, 1) * var).sum(0))
+            if nbt is not None:
+                nbt.add_(S)
+        ctx.save_for_backward(x, mean, var, gm, bt)
+        ctx.cfg = (S, B, C, HW, eps, act, slope, gamma is not None, nscr)
+        ctx.world = world
+        ctx.mark_non_differentiable(mean, var)
+        return y, mean, var
+
+    @staticmethod
     def backward(ctx, g, _gm, _gv):
         x, mean, var, gm, bt = ctx.saved_tensors
         S, B, C, HW, eps, act, slope, affine, nscr = ctx.cfg
@@ -1573,7 +1616,13 @@ class StepBatchNormActFn(torch.autograd.Function):
         gx = torch.empty_like(x)
         ggamma = torch.empty((C,), device=x.device, dtype=torch.float32) if affine else None
         gbeta = torch.empty((C,), device=x.device, dtype=torch.float32) if affine else None
-        L.call("rfn_stepbn_bwd_f32", L.dev(x), L.dev(gm), L.dev(bt), L.dev(g), L.dev(mean), L.dev(var), L.dev(sums),
-               L.dev(gx), L.dev(ggamma), L.dev(gbeta), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act),
-               ctypes.c_float(slope))
+        args = (L.dev(x), L.dev(gm), L.dev(bt), L.dev(g), L.dev(mean), L.dev(var), L.dev(sums), L.dev(gx), L.dev(ggamma),
+                L.dev(gbeta), _i(S), _i(B), _i(C), _i(HW), ctypes.c_float(eps), _i(act), ctypes.c_float(slope))
+        if ctx.world > 1:   # synchronised: partial sums, added over the ranks, apply
+            from . import dist as rdist
+            L.call("rfn_stepbn_bwd_f32", *args, _i(1), _i(ctx.world))
+            rdist.all_reduce_sum_(sums)
+            L.call("rfn_stepbn_bwd_f32", *args, _i(2), _i(ctx.world))
+        else:
+            L.call("rfn_stepbn_bwd_f32", *args, _i(0), _i(1))
         return gx, ggamma, gbeta, None, None, None, None, None
