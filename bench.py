@@ -143,7 +143,7 @@ def kernel_roofline(rec, steps):
     # HBM traffic of the dominant kernel comes from separate rocprofv3 --pmc passes of this same workload (FETCH_SIZE /
     # WRITE_SIZE cannot be read from inside the process); the committed summary is attached when it is for this kernel
     try:
-        with open(os.path.join(ROOT, "profiles", "r02_pmc_dominant_traffic.json")) as f:
+        with open(os.path.join(ROOT, "profiles", "r03_pmc_dominant_traffic.json")) as f:
             pmc = json.load(f)
         if pmc.get("kernel") and pmc["kernel"] in dom:
             # the figure belongs to the kernel source it was measured on: dropped (null + traffic_stale) when that file changed
@@ -154,7 +154,8 @@ def kernel_roofline(rec, steps):
                 roof["traffic_stale"] = True
                 raise ValueError("stale")
             roof["traffic"] = pmc["traffic_bytes_per_launch"]
-            roof["traffic_source"] = "profiles/r02_pmc_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes)"
+            roof["traffic_source"] = ("profiles/r03_pmc_dominant_traffic.json (rocprofv3 --pmc FETCH_SIZE, WRITE_SIZE passes; "
+                                      "mean over the launches of every instantiation of the template)")
     except (OSError, ValueError):
         pass
     table = sorted(([k, v["calls"] // steps, round(v["ms"] / steps, 3),

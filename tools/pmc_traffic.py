@@ -7,6 +7,8 @@ def sha16(rel):
     return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
 # the source file of each kernel whose traffic has been measured: bench.py drops the figure when the source changed
 KERNEL_SOURCE = {"coupling_po_fwd_kernel": "recurrent-flows-msc_amd/csrc/coupling_po.hip",
+                 "coupling_po_bwd": "recurrent-flows-msc_amd/csrc/coupling_po.hip",
+                 "gemm_wgrad_b3_kernel": "recurrent-flows-msc_amd/csrc/wgrad_bf16x3.hip",
                  "conv1x1_ws_kernel": "recurrent-flows-msc_amd/csrc/conv_bf16x3.hip"}
 def mean_kb(d, counter, sym):
     f = glob.glob(d + "/*/*counter_collection.csv")[0]

@@ -27,6 +27,13 @@ def cat(n):
         return "MINE:shell"
     return n[:90]
 by_grid = len(sys.argv) > 3 and sys.argv[3] == "grid"  # keep launches of different grid sizes (= shapes) apart
+by_template = len(sys.argv) > 3 and sys.argv[3] == "template"  # the instantiations of one kernel template on one line
+if by_template:
+    import re
+    _cat = cat
+    def cat(n):  # noqa: F811
+        k = _cat(n)
+        return k if k.startswith("MINE:") else re.sub(r"<.*", "", re.sub(r"^void ", "", k)).strip()[:90]
 for r in seg:
     key = cat(r["Kernel_Name"])
     if by_grid and "Grid_Size_X" in r:
