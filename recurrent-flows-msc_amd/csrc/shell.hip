@@ -974,12 +974,41 @@ __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParam
         const int n0 = (int)(((long)blockIdx.x * PB) / HW);
         float* out = a.logdet + (long)blockIdx.x * a.ld_slots;
         if ((long)n0 * HW <= (long)blockIdx.x * PB && ((long)blockIdx.x * PB + PB) <= (long)(n0 + 1) * HW) {
-            // the whole block lies inside frame n0 (the shallow levels): butterfly per wave, four waves in order
-            const float tot = wave_sum(contrib);
+            // the whole block lies inside frame n0 (the shallow levels): DPP butterfly per wave, four waves in order
+            const float tot = wave_sum_dpp(contrib);
             if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = tot;
             __syncthreads();
             if (threadIdx.x == 0) out[0] = (red[0] + red[1]) + (red[2] + red[3]);
             if (threadIdx.x > 0 && threadIdx.x < a.ld_slots) out[threadIdx.x] = 0.f;
+        } else if ((HW & (HW - 1)) == 0 && HW < PB && HW >= 4) {
+            // power-of-two maps smaller than the block (the deep levels): the block starts on a frame boundary.  Groups of
+            // G = min(HW, 64) consecutive threads lie in one frame: DPP sums inside the group, then thread f adds the
+            // groups of frame f in increasing order
+            const int G = HW < 64 ? HW : 64;
+            float v = valid ? contrib : 0.f;
+            if (G == 64) {
+                v = wave_sum_dpp(v);
+            } else {
+#define RFN_DPP_ADD_(ctrl) v += __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), ctrl, 0xF, 0xF, true))
+                RFN_DPP_ADD_(0xB1);                 // quad_perm [1,0,3,2]
+                RFN_DPP_ADD_(0x4E);                 // quad_perm [2,3,0,1]
+                if (G >= 8) RFN_DPP_ADD_(0x141);    // row_half_mirror
+                if (G >= 16) RFN_DPP_ADD_(0x140);   // row_mirror
+#undef RFN_DPP_ADD_
+                if (G >= 32) v += __shfl_xor(v, 16, 64);
+            }
+            if ((threadIdx.x & (G - 1)) == 0) red[threadIdx.x / G] = v;
+            __syncthreads();
+            const int F = PB / HW, ngrp = 256 / G, gpf = HW / G;   // groups per (frame, channel group)
+            if (threadIdx.x < F) {
+                float tot = 0.f;
+                for (int k = 0; k < ngrp; ++k)
+                    if (((k * G) & (PB - 1)) / HW == (int)threadIdx.x) tot += red[k];
+                (void)gpf;
+                out[threadIdx.x] = tot;
+            } else if (threadIdx.x < a.ld_slots) {
+                out[threadIdx.x] = 0.f;
+            }
         } else {
             red[threadIdx.x] = valid ? contrib : 0.f;
             __syncthreads();

@@ -410,3 +410,21 @@ def test_bench_self_launches_its_ranks(tmp_path, capsys):
     assert rc == 7 and time.time() - t0 < 60
     assert bench._gpus_arg(["--steps", "3", "--gpus", "4"]) == 4 and bench._gpus_arg(["--gpus=2"]) == 2
     assert bench._gpus_arg(["--steps", "3"]) == 1
+
+
+def test_checkpoint_args_follow_the_world_size():
+    """a data-parallel checkpoint stores the per-rank batch in `args` and the global batch beside it; resuming on
+    another number of ranks (or on one process) rebuilds the Solver with the global batch divided over the new ranks
+    (the file must describe ONE process on the global batch)."""
+    from RFN.trainer import Solver
+    args = Namespace(batch_size=4, x_dim=[4, 1, 64, 64], condition_dim=[4, 1, 64, 64], multigpu=True)
+    ckpt = {"args": args, "global_batch_size": 32, "world_size": 8}
+    a1 = Solver.args_for_world(ckpt, 1)
+    assert a1.batch_size == 32 and a1.x_dim == [32, 1, 64, 64] and a1.condition_dim[0] == 32
+    a2 = Solver.args_for_world(ckpt, 2)
+    assert a2.batch_size == 16 and a2.x_dim[0] == 16
+    assert args.batch_size == 4 and args.x_dim[0] == 4          # the stored Namespace is not modified
+    with pytest.raises(ValueError):
+        Solver.args_for_world(ckpt, 5)
+    # a reference checkpoint (single process, no global_batch_size entry): the stored batch is the global one
+    assert Solver.args_for_world({"args": args}, 2).batch_size == 2

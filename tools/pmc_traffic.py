@@ -11,7 +11,7 @@ KERNEL_SOURCE = {"coupling_po_fwd_kernel": "recurrent-flows-msc_amd/csrc/couplin
                  "gemm_wgrad_b3_kernel": "recurrent-flows-msc_amd/csrc/wgrad_bf16x3.hip",
                  "conv1x1_ws_kernel": "recurrent-flows-msc_amd/csrc/conv_bf16x3.hip"}
 def mean_kb(d, counter, sym):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
             if r["Counter_Name"] == counter and sym in r["Kernel_Name"]]
     return sum(vals) / len(vals), len(vals)
@@ -25,7 +25,7 @@ out = {"kernel": sys.argv[3], "dispatches": [n1, n2], "fetch_bytes_per_launch": 
 json.dump(out, open(sys.argv[4], "w"), indent=1)
 # per-kernel aggregate of both passes next to the summary (the raw counter_collection.csv files are hundreds of MB)
 def by_kernel(d, counter):
-    f = glob.glob(d + "/*/*counter_collection.csv")[0]
+    f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     agg = {}
     for r in csv.DictReader(open(f)):
         if r["Counter_Name"] == counter:
