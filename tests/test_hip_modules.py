@@ -1288,6 +1288,54 @@ def test_glow_level_node_equals_chain_of_step_nodes(conv_precision, N, C, Cc, S,
         close(a, b.cpu(), 1e-4, 1e-6)
 
 
+@pytest.mark.parametrize("N,C,Cc,S,Kn,act", [(3, 4, 16, 32, 2, "relu"), (2, 8, 32, 16, 3, "leakyrelu")])
+def test_fused_backward_chain_equals_unfused_backward(conv_precision, N, C, Cc, S, Kn, act, monkeypatch):
+    """the level node with the fused coupling-net backward (rfn_coupling_po_bwd: one kernel from the forward kernel's
+    activation masks, ActNorm gradients from the weight gradients) against the same node with RFN_COUPLING_PO_BWD=0 (two
+    data-gradient kernels that read h1 / h2 and sum g*y themselves): every gradient -- input, condition, InvConv
+    matrices, all 13 parameters of every step -- within the gradients' tolerance (the two paths use different split
+    arithmetics: f16x3s vs bf16x3).  Covers the A/B switch the product keeps (switches multiply paths)."""
+    if conv_precision != "mixed":
+        pytest.skip("the fused kernels are the path of the 'mixed' arithmetic")
+    from rfn_hip import ops as K
+    g = torch.Generator().manual_seed(90 + C)
+    Ch, Hd = C // 2, 256
+
+    def leaf(*shape, scale=1.0):
+        return (torch.randn(*shape, generator=g) * scale).cuda().requires_grad_(True)
+
+    x, cond = leaf(N, C, S, S), leaf(N, Cc, S, S)
+    Wst = (torch.eye(C).expand(Kn, C, C) + 0.2 * torch.randn(Kn, C, C, generator=g)).cuda().requires_grad_(True)
+    steps = []
+    for _ in range(Kn):
+        steps.append([leaf(1, C, 1, 1, scale=0.1), leaf(1, C, 1, 1, scale=0.1),
+                      leaf(Hd, Ch + Cc, 3, 3, scale=0.05), leaf(1, Hd, 1, 1, scale=0.1), leaf(1, Hd, 1, 1, scale=0.1),
+                      leaf(Hd, Hd, 1, 1, scale=0.05), leaf(1, Hd, 1, 1, scale=0.1), leaf(1, Hd, 1, 1, scale=0.1),
+                      leaf(C, Hd, 3, 3, scale=0.02), leaf(C, scale=0.1), leaf(C, 1, 1, scale=0.1),
+                      leaf(Ch, 1, 1, scale=0.5), leaf(Ch, 1, 1, scale=0.1)])
+    plan = K.POPackPlan([(st[2].detach(), st[5].detach(), st[8].detach()) for st in steps])
+    plan.run()
+    assert all(b is not None for b in plan.bwd_bufs) and K.coupling_po_bwd_ok(N, C, S, S)
+    packs = [(None,) * 6 + (plan.bufs[k], plan.bwd_bufs[k]) for k in range(Kn)]
+    gout = torch.randn(N, C, S, S, generator=g).cuda()
+    gdl = torch.randn(N, generator=g).cuda()
+    leaves = [x, cond, Wst] + [t for st in steps for t in st]
+
+    def run(fused):
+        monkeypatch.setenv("RFN_COUPLING_PO_BWD", "1" if fused else "0")
+        for t in leaves:
+            t.grad = None
+        out, dl = K.GlowLevelFn.apply(x, cond, Wst, K.ACT[act], K.CLAMP["realnvp"], packs, *[t for st in steps for t in st])
+        ((out * gout).sum() + (dl * gdl).sum()).backward()
+        return out.detach().clone(), [t.grad.detach().clone() for t in leaves]
+
+    o0, g0 = run(False)
+    o1, g1 = run(True)
+    assert torch.equal(o0, o1)          # the forward pass is the same launches either way (and bit-reproducible)
+    for a, b in zip(g1, g0):
+        close(a, b.cpu(), 2e-3, 1e-7)
+
+
 @pytest.mark.parametrize("C,Kn,hw", [(4, 10, 1024), (64, 3, 4), (24, 16, 64), (96, 2, 64), (6, 3, 16)])
 def test_invconv_weights_kernel_equals_torch_algebra(conv_precision, C, Kn, hw, monkeypatch):
     """rfn_invconv_weights_{fwd,bwd}_f32 (InvConv.get_weight of the K steps of a level, glow_modules.py:178-207, in one
