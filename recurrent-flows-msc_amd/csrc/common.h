@@ -27,7 +27,8 @@ void rfn_set_error(const char* fmt, ...);
         }                                                                     \
     } while (0)
 
-// Per-device scratch buffer of the split-K convolutions (grow-only, owned by the library, freed at process exit): the K
+// Per-device scratch buffer of the split-K convolutions (grow-only, owned by the library, released at process exit;
+// an outgrown buffer stays allocated because captured hipGraphs may still point into it): the K
 // slices of a split convolution write their partial outputs here and a second kernel adds them in a fixed order -- no
 // order-dependent float atomics in any convolution.  Returns nullptr (error set) when the buffer would have to grow
 // while `s` is being captured into a hipGraph: run the same shapes eagerly once before capturing.  One buffer per device

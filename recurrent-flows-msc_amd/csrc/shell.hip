@@ -17,6 +17,7 @@ extern "C" int rfn_abi_version(void) { return 1; }
 
 #include <map>
 #include <mutex>
+#include <vector>
 float* rfn_workspace(hipStream_t s, size_t floats) {
     // ONE buffer per device, whatever the stream: a hipGraph is captured on a fresh stream of its own, which must find
     // the buffer its eager warm-up runs (on other streams) have grown.  Consequence, stated in include/rfn_hip.h: split-K
@@ -33,10 +34,14 @@ float* rfn_workspace(hipStream_t s, size_t floats) {
         rfn_set_error("split-K workspace must grow to %zu floats during a hipGraph capture: run this shape eagerly first", floats);
         return nullptr;
     }
-    if (e.first) (void)hipFree(e.first);   // (synchronises with the device: nothing in flight still uses it)
+    // An outgrown buffer is NOT freed: a captured hipGraph has its address baked into kernel arguments and may be replayed
+    // after an eager call of a larger shape made the buffer grow (generation between training steps).  Growth is geometric,
+    // so the retired buffers add up to less than the live one; all of them go with the process.
+    static std::vector<float*> retired;
+    if (e.first) retired.push_back(e.first);
     e.first = nullptr;
     e.second = 0;
-    const size_t want = floats + floats / 4 + 1024;
+    const size_t want = 2 * floats + 1024;
     float* ptr = nullptr;
     if (hipMalloc(&ptr, want * sizeof(float)) != hipSuccess) {
         rfn_set_error("split-K workspace: hipMalloc of %zu bytes failed", want * sizeof(float));
