@@ -59,9 +59,12 @@ class Solver(object):
         if self.multigpu and self.world > 1 and not dist.is_initialized():
             local = int(os.environ.get("LOCAL_RANK", 0))
             if torch.cuda.is_available():
+                if os.environ.get("RFN_SINGLE_GPU"):
+                    local = 0
                 torch.cuda.set_device(local)
                 self.device = torch.device("cuda", local)
-            dist.init_process_group("nccl" if torch.cuda.is_available() else "gloo")
+            # (RFN_DIST_BACKEND=gloo: rehearsal with several ranks on one GPU, as in bench.py and the tests)
+            dist.init_process_group(os.environ.get("RFN_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo"))
         self.train_loader, self.test_loader = self.create_loaders()
         if self.rank == 0:
             os.makedirs(self.path + "png_folder", exist_ok=True)

@@ -1052,6 +1052,67 @@ print("rank %d ok" % rank)
 """
 
 
+_DP_TRAIN_WORKER = r"""
+import os, sys
+os.environ.setdefault("DEBUG_CLR_GRAPH_PACKET_CAPTURE", "0")
+root = sys.argv[1]
+sys.path.insert(0, root); sys.path.insert(0, os.path.join(root, "recurrent-flows-msc_amd"))
+import torch
+from tests.test_hip_modules import _tiny_solver_args
+from RFN.trainer import Solver
+args = _tiny_solver_args(sys.argv[2], 2)          # per-rank batch 2 -> global batch 4
+args.synthetic_data, args.multigpu, args.digit_size, args.max_steps, args.n_epochs = True, True, 8, 2, 1
+s = Solver(args)
+s.build()                                          # process group (gloo, both ranks on this GPU), loaders, model, HipAdam
+assert s.world == 2 and type(s.optimizer).__name__ == "HipAdam"
+s.train()                                          # two steps, the end-of-epoch consensus, the checkpoint collective
+print("rank %d trained, counter %d" % (s.rank, s.counter))
+"""
+
+
+def test_data_parallel_solver_train_and_resume(tmp_path, conv_precision):
+    """ADVICE r2 (high / medium): a two-rank `Solver.train()` reaches the end of its epoch -- the loss / stop consensus
+    (host scalars through the process group), the checkpoint collective -- and writes a file that describes ONE process
+    on the global batch: the gathered rows of the sharded initial states AND of their Adam moments, the global batch size
+    beside the per-rank args.  A single process then resumes it (`Solver.args_for_world`, `Solver.load`: the moments have
+    their parameters' sizes, which HipAdam checks) and takes a step."""
+    if conv_precision != "mixed":
+        pytest.skip("arithmetic-independent protocol: run once")
+    import subprocess, sys as _sys, os as _os
+    from tests.conftest import ROOT
+    from RFN.trainer import Solver
+    script = tmp_path / "dp_train_worker.py"
+    script.write_text(_DP_TRAIN_WORKER)
+    rel = "/" + _os.path.relpath(str(tmp_path), _os.getcwd()) + "/"
+    env = dict(_os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29751", WORLD_SIZE="2", OMP_NUM_THREADS="2",
+               RFN_DIST_BACKEND="gloo", RFN_SINGLE_GPU="1")
+    procs = [subprocess.Popen([_sys.executable, str(script), ROOT, rel], env=dict(env, RANK=str(r), LOCAL_RANK=str(r)),
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, cwd=_os.getcwd()) for r in range(2)]
+    outs = [p.communicate(timeout=600)[0] for p in procs]
+    for r, (p, o) in enumerate(zip(procs, outs)):
+        assert p.returncode == 0 and "rank %d trained, counter 2" % r in o, "rank %d failed:\n%s" % (r, o[-3000:])
+    ckpt = Solver.read_checkpoint(str(tmp_path / "model_folder" / "rfn.pt"))
+    assert ckpt["world_size"] == 2 and ckpt["global_batch_size"] == 4 and ckpt["args"].batch_size == 2
+    sd, osd = ckpt["model_state_dict"], ckpt["optimizer_state_dict"]
+    assert sd["h_0"].shape[0] == 4 and sd["z_0"].shape[0] == 4
+    args1 = Solver.args_for_world(ckpt, 1)
+    assert args1.batch_size == 4
+    args1.multigpu = False
+    s = Solver(args1)
+    s.build()
+    names = [n for n, _ in s.model.named_parameters()]
+    assert tuple(osd["state"][names.index("h_0")]["exp_avg"].shape) == tuple(sd["h_0"].shape)   # gathered moments
+    s.load(ckpt)
+    for n, p in s.model.named_parameters():
+        st = s.optimizer.state.get(p)
+        if st:
+            assert st["exp_avg"].shape == p.shape, n
+    x = next(iter(s.train_loader))
+    s.train_step(x.cuda())                          # HipAdam builds its table: sizes agree
+    s.flush_log()
+    assert s.counter == 3
+
+
 def test_data_parallel_rfn_equals_single_process_global_batch(tmp_path, conv_precision):
     """two fresh processes (gloo, both on this GPU) shard a global batch of 4 sequences: after the first-step protocol of
     Solver.train_step (rank-0 ActNorm init broadcast) the averaged gradients of every shared parameter, the gradients
