@@ -180,9 +180,32 @@ def test_glowstep_canonical_level0(golden):
     a = dict(GLOW_DEFAULTS)
     a["n_units_affine"] = 256
     gs = load_sd(GlowStep([1, 4, 32, 32], [1, 16, 32, 32], glow_ns(a)), f["sd"]).train()
-    y, ld = gs(cu(f["x"]), cu(f["cond"]), torch.zeros(1, device="cuda"), False)
+    x = cu(f["x"]).requires_grad_(True)
+    c = cu(f["cond"]).requires_grad_(True)
+    y, ld = gs(x, c, torch.zeros(1, device="cuda"), False)
     close(y, f["y"], 1e-4, 1e-4)
     close(ld, f["logdet"], 1e-4, 1e-4)
+    # backward at the canonical width (Hd = 256, one 32x32 frame: the fused forward / backward kernels of the shallow
+    # levels in 'mixed') against the oracle's autograd on the same weights -- the fixture pins the oracle's forward
+    g = torch.Generator().manual_seed(5)
+    wgt, gld = torch.randn(1, 4, 32, 32, generator=g), torch.randn(1, generator=g)
+    ((y * cu(wgt)).sum() + (ld * cu(gld)).sum()).backward()
+    sd = {k: (v.float() if v.dtype == torch.float16 else v).clone() for k, v in f["sd"].items()}
+    for k, v in sd.items():
+        if v.is_floating_point() and "initialized" not in k and k.split(".")[-1] not in ("p", "sign_s"):
+            v.requires_grad_(True)
+    xo, co = f["x"].clone().requires_grad_(True), f["cond"].clone().requires_grad_(True)
+    yo, ldo = O.glowstep(sd, "", xo, co, torch.zeros(1), False, True, a["non_lin_glow"], a["clamp_type"])
+    ((yo * wgt).sum() + (ldo * gld).sum()).backward()
+    rel = lambda a_, b_: float((a_.detach().cpu() - b_).norm() / (b_.norm() + 1e-30))
+    assert rel(x.grad, xo.grad) <= 5e-3 and rel(c.grad, co.grad) <= 5e-3
+    named = dict(gs.named_parameters())
+    n_checked = 0
+    for k, v in sd.items():
+        if v.requires_grad and v.grad is not None and k in named and named[k].grad is not None and float(v.grad.norm()) > 1e-12:
+            assert rel(named[k].grad, v.grad) <= 5e-3, (k, rel(named[k].grad, v.grad))
+            n_checked += 1
+    assert n_checked >= 12
 
 
 @pytest.mark.parametrize("name", ["listglow_L2K2", "listglow_L3K2_rgb_leaky_glowclamp", "listglow_uncond"])
