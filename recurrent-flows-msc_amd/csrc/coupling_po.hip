@@ -71,17 +71,33 @@ __host__ __device__ static inline POGeom po_geom(int Cin, int C, bool bwd = fals
     return g;
 }
 
-// group `idx` (0 .. 2 NG + 11) of a round in consumption order: first fragment and fragment count
+// Grouping of the stream for the LDS ring (the stream itself is linear in the k-step, so the grouping is the kernel's
+// choice): conv1 groups of GS1 k-steps (8 GS1 fragments; NG1 = 5 NG / GS1 groups per quad), conv2 groups of 2 k-steps
+// (32 fragments), conv3 groups of GS3 k-steps (2 NP GS3 fragments).  The canonical shallow levels (NG <= 5) take
+// GS1 = 5, GS3 = 4 (slots of 40 KB); wider inputs (NG = 9: level 2 of the canonical flow, the BAIR flow's level 0) need
+// the LDS for the input image and take GS1 = 3, GS3 = 2 (slots of 32 KB).
+__host__ __device__ constexpr int po_gs1(int NG) { return NG > 5 ? 3 : 5; }
+__host__ __device__ constexpr int po_gs3(int NP) { return NP > 3 ? 2 : 4; }
+// group `idx` (0 .. 2 NG1 + 8 + 16 / GS3 - 1) of a round in consumption order: first fragment and fragment count
 __host__ __device__ constexpr int po_group_base(int NG, int NP, int idx) {
-    const int QF = NG * 40 + 128;
-    return idx < NG ? 1 + idx * 40
-         : idx < NG + 4 ? 1 + NG * 40 + (idx - NG) * 32
-         : idx < 2 * NG + 4 ? 1 + QF + (idx - NG - 4) * 40
-         : idx < 2 * NG + 8 ? 1 + QF + NG * 40 + (idx - 2 * NG - 4) * 32
-         : 1 + 2 * QF + (idx - 2 * NG - 8) * 8 * NP;
+    const int QF = NG * 40 + 128, GS1 = po_gs1(NG), NG1 = 5 * NG / GS1, F1 = 8 * GS1;
+    return idx < NG1 ? 1 + idx * F1
+         : idx < NG1 + 4 ? 1 + NG * 40 + (idx - NG1) * 32
+         : idx < 2 * NG1 + 4 ? 1 + QF + (idx - NG1 - 4) * F1
+         : idx < 2 * NG1 + 8 ? 1 + QF + NG * 40 + (idx - 2 * NG1 - 4) * 32
+         : 1 + 2 * QF + (idx - 2 * NG1 - 8) * 2 * NP * po_gs3(NP);
+}
+// positions of the haloed input image of a round on W x W maps (see the kernel)
+__host__ __device__ constexpr int po_image_positions(int W) {
+    return W * W >= PO_ROUND_PX ? (PO_ROUND_PX / W + 2) * (W + 2) : (PO_ROUND_PX / (W * W)) * (W + 2) * (W + 2);
+}
+__host__ __device__ constexpr int po_slot_frags(int NG, int NP) {   // fragments (KB) per ring slot
+    const int f1 = 8 * po_gs1(NG), f3 = 2 * NP * po_gs3(NP);
+    return (f1 > 32 ? f1 : 32) > f3 ? (f1 > 32 ? f1 : 32) : f3;
 }
 __host__ __device__ constexpr int po_group_size(int NG, int NP, int idx) {
-    return idx < NG ? 40 : idx < NG + 4 ? 32 : idx < 2 * NG + 4 ? 40 : idx < 2 * NG + 8 ? 32 : 8 * NP;
+    const int GS1 = po_gs1(NG), NG1 = 5 * NG / GS1, F1 = 8 * GS1;
+    return idx < NG1 ? F1 : idx < NG1 + 4 ? 32 : idx < 2 * NG1 + 4 ? F1 : idx < 2 * NG1 + 8 ? 32 : 2 * NP * po_gs3(NP);
 }
 
 // ------------------------------------------------------------------------------------------------ weight stream
@@ -352,15 +368,30 @@ __device__ __forceinline__ int po_exp_of(const float m) {
 // m1 = mask of h2, m2 = mask of h1.
 template <int NG, int NP, int LOGW, int ACT, bool BWD>
 __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const POFwdParams p) {
-    // square maps of side W = 2^LOGW: a round is 128 / W image rows; its haloed image has IW columns, IPOS positions
-    constexpr int W = 1 << LOGW, HW = W * W, IW = W + 2, IPOS = (PO_ROUND_PX / W + 2) * IW;
+    // square maps of side W = 2^LOGW.  A round is 128 consecutive pixels: 128 / W image rows of one frame (H W >= 128) or
+    // FPR = 128 / (H W) whole frames (8x8 maps: two).  Its haloed image: per frame part (RROWS + 2) rows of IW columns.
+    constexpr int W = 1 << LOGW, HW = W * W, IW = W + 2;
+    constexpr int FPR = HW >= PO_ROUND_PX ? 1 : PO_ROUND_PX / HW;
+    constexpr int RROWS = HW >= PO_ROUND_PX ? PO_ROUND_PX / W : W;
+    constexpr int FPOS = (RROWS + 2) * IW, IPOS = FPR * FPOS;
     constexpr int PO_ITEMS = (NG * IPOS + 64 * PO_WAVES - 1) / (64 * PO_WAVES);   // staging items per thread
-    constexpr int RPF_SHIFT = 2 * LOGW - 7;   // log2(rounds per frame)
-    constexpr int G3 = 8 * NP;                 // fragments per conv3 group
-    constexpr int SLOTF = 40 > G3 ? 40 : G3;
+    constexpr int RPF_SHIFT = HW >= PO_ROUND_PX ? 2 * LOGW - 7 : 0;   // log2(rounds per frame)
+    constexpr int GS1 = po_gs1(NG), NG1 = 5 * NG / GS1;   // conv1: k-steps per ring group, groups per quad
+    constexpr int GS3 = po_gs3(NP), NG3 = 16 / GS3;       // conv3: k-steps per ring group, groups
+    constexpr bool RT = NG > 5;   // conv1 as run-time loops over channel groups inside the (unrolled) tap pairs
+    // The next round's image is loaded one quad ahead into registers (8 PO_ITEMS of them) -- where the register file has
+    // room.  The wide instantiations are at the 512-register limit without them (scratch spills otherwise) and load the
+    // image when its LDS buffer is free, right before converting it: the tensors were written by the launch before this
+    // one and come from L2 / the Infinity Cache.
+    constexpr bool LATE = RT || (BWD && NG > 1);
+    static_assert((5 * NG) % GS1 == 0 && (!RT || NG % GS1 == 0), "conv1 grouping");
+    constexpr int G3 = 2 * NP * GS3;           // fragments per conv3 group
+    constexpr int Y1 = 2 * GS1, Y3 = G3 / 4;   // LDS-DMA instructions per wave of a conv1 / conv3 group (conv2: 8)
+    static_assert(G3 % 4 == 0, "a group's fragments are shared evenly by the four waves");
+    constexpr int SLOTF = po_slot_frags(NG, NP);
     constexpr int SLOT = SLOTF * 1024;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    constexpr int NGRP = 2 * NG + 8 + (BWD ? 0 : 4);                       // weight groups per round
+    constexpr int NGRP = 2 * NG1 + 8 + (BWD ? 0 : NG3);                    // weight groups per round
     float* par = reinterpret_cast<float*>(lds + 3 * SLOT);                 // [4][256]: b1, exp(l1), b2, exp(l2)
     float* red = par + 1024;                                               // [8] block reductions
     f16x8* img = reinterpret_cast<f16x8*>(lds + 3 * SLOT + 4096 + 64);      // [plane 2][NG][IPOS]
@@ -421,19 +452,24 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
     // (2) block maximum -> scale, conversion, LDS.  Item = (8-channel group, image position).
     float raw[PO_ITEMS][8];
     auto stage_load = [&](const int rnd) {
-        const int n_ = rnd >> RPF_SHIFT;
-        const int y0_ = ((rnd & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX) >> LOGW;
-        const float* zb = p.z + (long)n_ * p.z_ns;
-        const float* cb = p.cond + (long)n_ * p.cond_ns;
+        const int n0_ = FPR > 1 ? rnd * FPR : rnd >> RPF_SHIFT;
+        const int y0_ = FPR > 1 ? 0 : ((rnd & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX) >> LOGW;
+        // (wide instantiations: the items' decomposition is recomputed every round -- hoisted out of the round loop it is
+        // 70+ registers the kernel does not have, i.e. scratch)
+        int tid_ = tid;
+        if (LATE) asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int it = 0; it < PO_ITEMS; ++it) {
-            const int item = tid + it * 64 * PO_WAVES;
+            const int item = tid_ + it * 64 * PO_WAVES;
             const bool live = item < NG * IPOS;
             const int g = live ? item / IPOS : 0, pos = live ? item - g * IPOS : 0;
-            const int iy = pos / IW, ix = pos - iy * IW;
+            const int fr = FPR > 1 ? pos / FPOS : 0, rem = pos - fr * FPOS;
+            const int iy = rem / IW, ix = rem - iy * IW;
             const int gy = y0_ - 1 + iy, gx = ix - 1;
             const bool ok = live && gy >= 0 && gy < W && gx >= 0 && gx < W;
             const int off = ok ? gy * W + gx : 0;
+            const float* zb = p.z + (long)(n0_ + fr) * p.z_ns;
+            const float* cb = p.cond + (long)(n0_ + fr) * p.cond_ns;
 #pragma unroll
             for (int j = 0; j < 8; ++j) {
                 const int ci = 8 * g + j;
@@ -445,14 +481,17 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
     };
     float u1_next = 0.f;   // 1 / (image scale * weight scale) of the image staged last
     auto stage_finish = [&](const int rnd) {
-        const int y0_ = ((rnd & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX) >> LOGW;
+        const int y0_ = FPR > 1 ? 0 : ((rnd & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX) >> LOGW;
         float vm = 0.f;
+        int tid_ = tid;
+        if (LATE) asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int it = 0; it < PO_ITEMS; ++it) {
-            const int item = tid + it * 64 * PO_WAVES;
+            const int item = tid_ + it * 64 * PO_WAVES;
             const bool live = item < NG * IPOS;
             const int g = live ? item / IPOS : 0, pos = live ? item - g * IPOS : 0;
-            const int iy = pos / IW, ix = pos - iy * IW;
+            const int rem = FPR > 1 ? pos % FPOS : pos;
+            const int iy = rem / IW, ix = rem - iy * IW;
             const int gy = y0_ - 1 + iy, gx = ix - 1;
             const bool ok = live && gy >= 0 && gy < W && gx >= 0 && gx < W;
 #pragma unroll
@@ -472,7 +511,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         u1_next = __uint_as_float((unsigned)(Eimg - 14) << 23) * inv_w1;   // undoes image and weight scale
 #pragma unroll
         for (int it = 0; it < PO_ITEMS; ++it) {
-            const int item = tid + it * 64 * PO_WAVES;
+            const int item = tid_ + it * 64 * PO_WAVES;
             if (item < NG * IPOS) {
                 const int g = item / IPOS, pos = item - g * IPOS;
                 f16x8 hi, lo;
@@ -495,13 +534,15 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
     }
     for (; round < p.n_rounds; round += gridDim.x) {
         const bool more = round + (int)gridDim.x < p.n_rounds;
-        const int n = round >> RPF_SHIFT;
-        const int pix0 = (round & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX;   // first pixel of the round in its frame
-        const int y0 = pix0 >> LOGW;
+        // this lane's frame, its pixel there, and the first image row of the round in that frame
+        const int rp = 32 * wave + l31;                                      // pixel of the round
+        const int fr = FPR > 1 ? rp >> (2 * LOGW) : 0;                       // frame of the round
+        const int n = FPR > 1 ? round * FPR + fr : round >> RPF_SHIFT;
+        const int pix = FPR > 1 ? rp & (HW - 1) : (round & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX + rp;
+        const int y0 = FPR > 1 ? 0 : ((round & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX) >> LOGW;
         const float u1 = u1_next;
 
-        // this lane's pixel and its five tap-pair positions inside the image (lane half = tap of the pair)
-        const int pix = pix0 + 32 * wave + l31;
+        // its five tap-pair positions inside the image (lane half = tap of the pair)
         const int iy = (pix >> LOGW) - y0 + 1, ix = (pix & (W - 1)) + 1;
         const f16x8* bp[PO_TAP_PAIRS];
 #pragma unroll
@@ -509,7 +550,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
             const int tA = 2 * tp, tB = 2 * tp + 1 < 9 ? 2 * tp + 1 : 4;   // the padding tap reads the centre (zero weight)
             const int dy = kk ? (tB / 3 - 1) : (tA / 3 - 1);
             const int dx = kk ? (tB % 3 - 1) : (tA % 3 - 1);
-            bp[tp] = img + (iy + dy) * IW + ix + dx;
+            bp[tp] = img + fr * FPOS + (iy + dy) * IW + ix + dx;
         }
         // byte offset of (frame n, channel 4kk, this pixel) in h1 / h2 (both [N,256,H,W] with frame strides h*_ns)
         const unsigned vo1 = (unsigned)(((long)n * p.h1_ns + (long)(4 * kk) * HW + pix) * 4);
@@ -535,23 +576,42 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
 
 #pragma unroll
         for (int u = 0; u < 2; ++u) {
-            if (u == 1 && more) stage_load(round + (int)gridDim.x);   // next round's image: in flight under this quad
+            if (u == 1 && more && !LATE) stage_load(round + (int)gridDim.x);   // next round's image: in flight under this quad
             // ================= conv1, output tiles 4u .. 4u+3: NG groups of 5 k-steps, four MFMA chains
             f32x16 Q[4];
 #pragma unroll
             for (int t = 0; t < 4; ++t)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) Q[t][r] = 0.f;
+            // one k-step: three MFMAs per output tile (lo*hi, hi*lo, hi*hi), the next k-step's fragments read in between
+#define PO_C1_STEP(LAST, ANEXT, BNEXT)                                                                     \
+            do {                                                                                           \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][1], B[cur][0]);      \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                if (!(LAST)) {                                                                             \
+                    _Pragma("unroll") for (int t = 0; t < 4; ++t) {                                        \
+                        A[nxt][t][0] = fr[((ANEXT) * 4 + t) * 2 * 64];                                     \
+                        A[nxt][t][1] = fr[(((ANEXT) * 4 + t) * 2 + 1) * 64];                               \
+                    }                                                                                      \
+                    _Pragma("unroll") for (int pl = 0; pl < 2; ++pl) B[nxt][pl] = BNEXT;                   \
+                }                                                                                          \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][0], B[cur][1]);      \
+                _Pragma("unroll") for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][0], B[cur][0]);      \
+                __builtin_amdgcn_sched_barrier(0);                                                         \
+            } while (0)
+            if constexpr (!RT) {
 #pragma unroll
-            for (int gi = 0; gi < NG; ++gi) {
-                // younger than this group's DMA: the DMA of the next group (10 / 8 instructions per wave)
+            for (int gi = 0; gi < NG1; ++gi) {
+                // younger than this group's DMA: the DMA of the next group (Y1 / 8 instructions per wave)
                 // (+ the 8 PO_ITEMS image loads of the next round while they are in flight: quad 1, first two groups)
-                if (u == 1 && gi < 2 && more) {
-                    if (gi + 1 < NG) PO_BOUNDARY(u * (NG + 4) + gi, 10 + 8 * PO_ITEMS);
-                    else PO_BOUNDARY(u * (NG + 4) + gi, 8 + 8 * PO_ITEMS);
+                if (u == 1 && gi < 2 && more && !LATE) {
+                    if (gi + 1 < NG1) PO_BOUNDARY(u * (NG1 + 4) + gi, Y1 + 8 * PO_ITEMS);
+                    else PO_BOUNDARY(u * (NG1 + 4) + gi, 8 + 8 * PO_ITEMS);
                 } else {
-                    if (gi + 1 < NG) PO_BOUNDARY(u * (NG + 4) + gi, 10);
-                    else PO_BOUNDARY(u * (NG + 4) + gi, 8);
+                    if (gi + 1 < NG1) PO_BOUNDARY(u * (NG1 + 4) + gi, Y1);
+                    else PO_BOUNDARY(u * (NG1 + 4) + gi, 8);
                 }
                 const f16x8* fr = reinterpret_cast<const f16x8*>(lds + sl * SLOT) + lane;
                 f16x8 A[2][4][2], B[2][2];
@@ -561,31 +621,46 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
                     A[0][t][1] = fr[(t * 2 + 1) * 64];
                 }
 #pragma unroll
-                for (int pl = 0; pl < 2; ++pl) B[0][pl] = bp[(5 * gi) / NG][(pl * NG + (5 * gi) % NG) * IPOS];
+                for (int pl = 0; pl < 2; ++pl) B[0][pl] = bp[(GS1 * gi) / NG][(pl * NG + (GS1 * gi) % NG) * IPOS];
 #pragma unroll
-                for (int k = 0; k < 5; ++k) {
-                    const int s = 5 * gi + k, cur = k & 1, nxt = cur ^ 1;
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][1], B[cur][0]);
-                    __builtin_amdgcn_sched_barrier(0);
-                    if (k + 1 < 5) {
-#pragma unroll
-                        for (int t = 0; t < 4; ++t) {
-                            A[nxt][t][0] = fr[(((k + 1) * 4 + t) * 2) * 64];
-                            A[nxt][t][1] = fr[(((k + 1) * 4 + t) * 2 + 1) * 64];
-                        }
-#pragma unroll
-                        for (int pl = 0; pl < 2; ++pl) B[nxt][pl] = bp[(s + 1) / NG][(pl * NG + (s + 1) % NG) * IPOS];
-                    }
-                    __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][0], B[cur][1]);
-#pragma unroll
-                    for (int t = 0; t < 4; ++t) PO_MFMA(Q[t], A[cur][t][0], B[cur][0]);
-                    __builtin_amdgcn_sched_barrier(0);
+                for (int k = 0; k < GS1; ++k) {
+                    const int s = GS1 * gi + k, cur = k & 1, nxt = cur ^ 1;
+                    PO_C1_STEP(k + 1 == GS1, k + 1, bp[(s + 1) / NG][(pl * NG + (s + 1) % NG) * IPOS]);
                 }
             }
+            } else {
+            // wide inputs: k-step s = tp * NG + g with the tap pairs unrolled and the channel groups of a tap pair in a
+            // run-time loop over ring groups of GS1 (a fully unrolled round is 10 NG k-steps with compile-time
+            // addresses: at NG = 9 hipcc spills hundreds of SGPRs and its AGPR pass fails)
+#pragma unroll
+            for (int tp = 0; tp < PO_TAP_PAIRS; ++tp) {
+#pragma unroll 1
+                for (int gg = 0; gg < NG / GS1; ++gg) {
+                    const int gq = tp * (NG / GS1) + gg;          // ring group of the quad
+                    const int gidx = u * (NG1 + 4) + gq;          // ring group of the round
+                    // younger: the next group's DMA (at least Y1 instructions) -- and, in quad 1, the image loads of the
+                    // next round, issued before its first group and still in flight during its first two
+                    if (u == 1 && tp == 0 && gg < 2 && more && !LATE) PO_BOUNDARY(gidx, Y1 + 8 * PO_ITEMS);
+                    else PO_BOUNDARY(gidx, Y1);
+                    const f16x8* fr = reinterpret_cast<const f16x8*>(lds + sl * SLOT) + lane;
+                    const f16x8* bq = bp[tp] + (GS1 * gg) * IPOS;   // channel group GS1 gg of this tap pair, plane hi
+                    f16x8 A[2][4][2], B[2][2];
+#pragma unroll
+                    for (int t = 0; t < 4; ++t) {
+                        A[0][t][0] = fr[(t * 2) * 64];
+                        A[0][t][1] = fr[(t * 2 + 1) * 64];
+                    }
+#pragma unroll
+                    for (int pl = 0; pl < 2; ++pl) B[0][pl] = bq[(pl * NG) * IPOS];
+#pragma unroll
+                    for (int k = 0; k < GS1; ++k) {
+                        const int cur = k & 1, nxt = cur ^ 1;
+                        PO_C1_STEP(k + 1 == GS1, k + 1, bq[(pl * NG + k + 1) * IPOS]);
+                    }
+                }
+            }
+            }
+#undef PO_C1_STEP
             // ---- epilogue of the four tiles: ActNorm + act, store h1, per-pixel maximum
             float vmax = 0.f;
             unsigned mq[2] = {0u, 0u};   // forward: the quad's two mask words (words 2u, 2u+1 of the thread's uint4), stored at once
@@ -634,12 +709,12 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
             for (int g2 = 0; g2 < 4; ++g2) {
                 // younger: next group's DMA (8; after the last one 10 = conv1 or 2 NP = conv3) and, for the first two groups,
                 // the 64 h1 stores of the quad's epilogue
-                if (g2 < 2) PO_BOUNDARY(u * (NG + 4) + NG + g2, 8 + 64);
-                else if (g2 == 2) PO_BOUNDARY(u * (NG + 4) + NG + g2, 8);
-                else if (u == 0) PO_BOUNDARY(u * (NG + 4) + NG + g2, 10);
-                else if (!BWD) PO_BOUNDARY(u * (NG + 4) + NG + g2, 2 * NP);
-                else if (more) PO_BOUNDARY(u * (NG + 4) + NG + g2, 10);   // (next: the next round's first group)
-                else PO_BOUNDARY(u * (NG + 4) + NG + g2, 0);
+                if (g2 < 2) PO_BOUNDARY(u * (NG1 + 4) + NG1 + g2, 8 + 64);
+                else if (g2 == 2) PO_BOUNDARY(u * (NG1 + 4) + NG1 + g2, 8);
+                else if (u == 0) PO_BOUNDARY(u * (NG1 + 4) + NG1 + g2, Y1);
+                else if (!BWD) PO_BOUNDARY(u * (NG1 + 4) + NG1 + g2, Y3);
+                else if (more) PO_BOUNDARY(u * (NG1 + 4) + NG1 + g2, Y1);   // (next: the next round's first group)
+                else PO_BOUNDARY(u * (NG1 + 4) + NG1 + g2, 0);
                 const f16x8* fr = reinterpret_cast<const f16x8*>(lds + sl * SLOT) + lane;
                 f16x8 A[2][4][2];
 #pragma unroll
@@ -672,7 +747,10 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         }
 
         // the image buffer is free (every wave passed four barriers since its last conv1 read): next round's image
-        if (more) stage_finish(round + (int)gridDim.x);
+        if (more) {
+            if (LATE) stage_load(round + (int)gridDim.x);
+            stage_finish(round + (int)gridDim.x);
+        }
 
         // ================= h2 = act(ActNorm(conv2)): store, per-pixel maximum over all 256 channels, conversion
         const float u2 = __uint_as_float((unsigned)(Erun - 14) << 23) * inv_w2;
@@ -697,7 +775,11 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         const int E3 = po_exp_of(vmax2);
         const float sc3 = __uint_as_float((unsigned)(268 - E3) << 23);
         const float u3 = __uint_as_float((unsigned)(E3 - 14) << 23) * inv_w3;
-        f16x8 h2f[16][2];
+        // h2 as B fragments: converted at once (NP <= 3) or, where NP accumulators + fragments leave no room for all of
+        // them beside h2 itself, one k-step at a time from the accumulators as conv3 proceeds
+        constexpr bool LAZY3 = NP > 3;
+        f16x8 h2f[LAZY3 ? 1 : 16][2];
+        if constexpr (!LAZY3) {
 #pragma unroll
         for (int a2 = 0; a2 < 8; ++a2)
 #pragma unroll
@@ -707,21 +789,22 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
                 for (int j = 0; j < 8; ++j) w8[j] = acc2[a2][8 * sp + j];
                 po_split_f16(w8, sc3, h2f[2 * a2 + sp][0], h2f[2 * a2 + sp][1]);
             }
+        }
 
-        // ================= tap-expanded conv3: 4 groups of 4 k-steps, NP chains
+        // ================= tap-expanded conv3: NG3 groups of GS3 k-steps, NP chains
         f32x16 Pacc[NP];
 #pragma unroll
         for (int jt = 0; jt < NP; ++jt)
 #pragma unroll
             for (int r = 0; r < 16; ++r) Pacc[jt][r] = 0.f;
 #pragma unroll
-        for (int g3 = 0; g3 < 4; ++g3) {
-            // younger: next group's DMA (2 NP; after the last one the next round's first group, if any) and, for the first
+        for (int g3 = 0; g3 < NG3; ++g3) {
+            // younger: next group's DMA (Y3; after the last one the next round's first group, if any) and, for the first
             // two groups, the 128 h2 stores
-            if (g3 < 2) PO_BOUNDARY(2 * NG + 8 + g3, 2 * NP + 128);
-            else if (g3 == 2) PO_BOUNDARY(2 * NG + 8 + g3, 2 * NP);
-            else if (more) PO_BOUNDARY(2 * NG + 8 + g3, 10);
-            else PO_BOUNDARY(2 * NG + 8 + g3, 0);
+            if (g3 < 2) PO_BOUNDARY(2 * NG1 + 8 + g3, Y3 + 128);
+            else if (g3 + 1 < NG3) PO_BOUNDARY(2 * NG1 + 8 + g3, Y3);
+            else if (more) PO_BOUNDARY(2 * NG1 + 8 + g3, Y1);
+            else PO_BOUNDARY(2 * NG1 + 8 + g3, 0);
             const f16x8* fr = reinterpret_cast<const f16x8*>(lds + sl * SLOT) + lane;
             f16x8 A[2][NP][2];
 #pragma unroll
@@ -730,13 +813,20 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
                 A[0][jt][1] = fr[(jt * 2 + 1) * 64];
             }
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                const int s = 4 * g3 + k, cur = k & 1, nxt = cur ^ 1;
+            for (int k = 0; k < GS3; ++k) {
+                const int s = GS3 * g3 + k, cur = k & 1, nxt = cur ^ 1;
+                const int sf = LAZY3 ? 0 : s;
+                if constexpr (LAZY3) {
+                    float w8[8];
+#pragma unroll
+                    for (int j = 0; j < 8; ++j) w8[j] = acc2[s >> 1][8 * (s & 1) + j];
+                    po_split_f16(w8, sc3, h2f[0][0], h2f[0][1]);
+                }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][1], h2f[s][0]);
+                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][1], h2f[sf][0]);
                 __builtin_amdgcn_sched_barrier(0);
-                if (k + 1 < 4) {
+                if (k + 1 < GS3) {
 #pragma unroll
                     for (int jt = 0; jt < NP; ++jt) {
                         A[nxt][jt][0] = fr[(((k + 1) * NP + jt) * 2) * 64];
@@ -745,9 +835,9 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
                 }
                 __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][0], h2f[s][1]);
+                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][0], h2f[sf][1]);
 #pragma unroll
-                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][0], h2f[s][0]);
+                for (int jt = 0; jt < NP; ++jt) PO_MFMA(Pacc[jt], A[cur][jt][0], h2f[sf][0]);
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
@@ -786,9 +876,8 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
 
 template <int NG, int NP, int LOGW, int ACT, bool BWD>
 static int launch_po_fwd_t(const POFwdParams& p, hipStream_t s) {
-    constexpr int G3 = 8 * NP;
-    constexpr int SLOTF = 40 > G3 ? 40 : G3;
-    constexpr int W = 1 << LOGW, IPOS = (PO_ROUND_PX / W + 2) * (W + 2);
+    constexpr int SLOTF = po_slot_frags(NG, NP);
+    constexpr int W = 1 << LOGW, IPOS = po_image_positions(W);
     const size_t ldsz = (size_t)3 * SLOTF * 1024 + 4096 + 64 + (size_t)2 * NG * IPOS * 16 + (BWD ? PO_WAVES * 512 * 4 : 0);
     if (ldsz > 160 * 1024 || IPOS != p.IPOS) {
         rfn_set_error("coupling_po: %zu bytes of LDS / %d image positions (expected %d)", ldsz, p.IPOS, IPOS);
@@ -808,15 +897,24 @@ static int launch_po_fwd(const POFwdParams& p, hipStream_t s) {
     return launch_po_fwd_t<NG, NP, LOGW, 0, BWD>(p, s);
 }
 
+// instantiations of the forward kernel: (channel groups of conv1's input, row tiles of the tap-expanded conv3, map side)
+//   (3, 2, 32) / (5, 3, 16)   levels 0 / 1 of the canonical flow (Cin 18 / 36, C 4 / 8)
+//   (9, 5, 8)                 level 2 of the canonical flow (Cin 72, C 16): two frames per round
+//   (9, 4, 32)                level 0 of the BAIR-shaped flow (C = 12, Cin 65..72: 6 + 64 `with_skip` condition channels)
+static bool po_fwd_instance(int NG, int NP, int W) {
+    return (NG == 3 && NP == 2 && W == 32) || (NG == 5 && NP == 3 && W == 16) || (NG == 9 && NP == 5 && W == 8) ||
+           (NG == 9 && NP == 4 && W == 32);
+}
 // shapes the fused kernel takes (the host asks before choosing this path)
 extern "C" int rfn_coupling_po_supported(int N, int C, int Cc, int Hd, int H, int W) {
     if (N <= 0 || C <= 0 || C % 2 || Cc < 0 || H <= 0 || W <= 0) return 0;
     const POGeom g = po_geom(C / 2 + Cc, C);
     const bool pow2 = (H & (H - 1)) == 0 && (W & (W - 1)) == 0;
-    const bool inst = H == W && ((g.NG == 3 && g.NP == 2 && W == 32) || (g.NG == 5 && g.NP == 3 && W == 16));
+    const bool inst = H == W && po_fwd_instance(g.NG, g.NP, W);
     // output tensors are addressed with 32-bit byte offsets (buffer stores)
     const bool small = (long)N * PO_HD * H * W * 4 < (1L << 32);
-    return Hd == PO_HD && pow2 && W <= PO_ROUND_PX && (H * W) % PO_ROUND_PX == 0 && inst && small;
+    // a round is 128 consecutive pixels of the (frame, pixel) sequence: whole rounds only
+    return Hd == PO_HD && pow2 && W <= PO_ROUND_PX && ((long)N * H * W) % PO_ROUND_PX == 0 && inst && small;
 }
 
 /* floats per activation-mask tensor (as fp32 elements: 4 per (round, thread)) and per partial-sum buffer of the
@@ -829,10 +927,10 @@ extern "C" long rfn_coupling_po_bwd_part_floats(int N, int H, int W) {
 
 static void po_fill_geometry(POFwdParams& p, int N, int C, int H, int W, int act) {
     p.C = C; p.N = N; p.H = H; p.W = W; p.logW = ilog2(W); p.act = act;
-    p.rpf_shift = ilog2(H * W / PO_ROUND_PX);
+    p.rpf_shift = H * W >= PO_ROUND_PX ? ilog2(H * W / PO_ROUND_PX) : 0;
     p.n_rounds = (int)((long)N * H * W / PO_ROUND_PX);
     p.IW = W + 2;
-    p.IPOS = (PO_ROUND_PX / W + 2) * (W + 2);
+    p.IPOS = po_image_positions(W);
 }
 
 /* ---- a5 (fused)  AffineCoupling.net forward  (Flow/glow_modules.py:232-238 with :119-121, :139-142): see the header
@@ -862,6 +960,8 @@ extern "C" int rfn_coupling_po_fwd(const float* z, long z_ns, const float* cond,
     int rc = -4;
     if (g.NG == 3 && g.NP == 2 && W == 32) rc = launch_po_fwd<3, 2, 5>(p, (hipStream_t)stream);
     if (g.NG == 5 && g.NP == 3 && W == 16) rc = launch_po_fwd<5, 3, 4>(p, (hipStream_t)stream);
+    if (g.NG == 9 && g.NP == 5 && W == 8) rc = launch_po_fwd<9, 5, 3>(p, (hipStream_t)stream);
+    if (g.NG == 9 && g.NP == 4 && W == 32) rc = launch_po_fwd<9, 4, 5>(p, (hipStream_t)stream);
     if (rc) return rc;
     RFN_LAUNCH_CHECK();
     return 0;
@@ -876,10 +976,16 @@ extern "C" int rfn_coupling_po_fwd(const float* z, long z_ns, const float* cond,
  * wpk: rfn_coupling_po_pack_bwd stream.  part: rfn_coupling_po_bwd_part_floats(N, H, W) floats, WRITTEN: per-workgroup
  * sums over pixels of ga2 ([.][0][256]) and ga1 ([.][1][256]); rfn_coupling_po_bwd_finish turns them (and the weight
  * gradients) into the ActNorm gradients. */
+// instantiations: (channel groups of the gradient image, map side): (1, 32) / (1, 16) levels 0 / 1 of the canonical flow
+// (C 4 / 8), (2, 8) its level 2 (C 16), (2, 32) level 0 of the BAIR-shaped flow (C 12) -- the levels whose forward pass
+// runs on the fused kernel (the backward kernel needs its activation masks)
+static bool po_bwd_instance(int NG, int W) {
+    return (NG == 1 && (W == 32 || W == 16)) || (NG == 2 && (W == 8 || W == 32));
+}
 extern "C" int rfn_coupling_po_bwd_supported(int N, int C, int H, int W) {
-    if (N <= 0 || C <= 0 || C > 8 || H != W) return 0;
+    if (N <= 0 || C <= 0 || H != W) return 0;
     const bool small = (long)N * PO_HD * H * W * 4 < (1L << 32);
-    return (W == 32 || W == 16) && small;
+    return po_bwd_instance((C + 7) / 8, W) && ((long)N * H * W) % PO_ROUND_PX == 0 && small;
 }
 extern "C" int rfn_coupling_po_bwd(const float* go, long go_ns, const void* wpk, const float* n1l, const float* n2l,
                                    const float* m_h1, const float* m_h2, float* ga2, long ga2_ns, float* ga1,
@@ -900,8 +1006,11 @@ extern "C" int rfn_coupling_po_bwd(const float* go, long go_ns, const void* wpk,
     p.Ch = C; p.Cc = 0;
     po_fill_geometry(p, N, C, H, W, act);
     int rc = -4;
-    if (W == 32) rc = launch_po_fwd<1, 0, 5, true>(p, (hipStream_t)stream);
-    if (W == 16) rc = launch_po_fwd<1, 0, 4, true>(p, (hipStream_t)stream);
+    const int NGb = (C + 7) / 8;
+    if (NGb == 1 && W == 32) rc = launch_po_fwd<1, 0, 5, true>(p, (hipStream_t)stream);
+    if (NGb == 1 && W == 16) rc = launch_po_fwd<1, 0, 4, true>(p, (hipStream_t)stream);
+    if (NGb == 2 && W == 8) rc = launch_po_fwd<2, 0, 3, true>(p, (hipStream_t)stream);
+    if (NGb == 2 && W == 32) rc = launch_po_fwd<2, 0, 5, true>(p, (hipStream_t)stream);
     if (rc) return rc;
     RFN_LAUNCH_CHECK();
     return 0;

@@ -238,12 +238,12 @@ class POPackPlan:
         self.table = torch.from_numpy(rec.view(np.uint8).copy()).to(dev)
 
         # the backward kernel's streams (w3 transposed + mirrored, w2 transposed) for the nets whose gradient image has
-        # at most 8 channels (rfn_coupling_po_bwd_supported)
+        # at most 16 channels (two 8-channel groups: rfn_coupling_po_bwd_supported)
         self.bwd_bufs = [None] * len(self.nets)
         recb = []
         for i, (w1, w2, w3) in enumerate(self.nets):
             C = int(w3.shape[0])
-            if C <= 8:
+            if C <= 16:
                 buf = torch.empty(int(lib.rfn_coupling_po_bwd_packed_bytes(C)) // 4, device=dev, dtype=torch.float32)
                 self.bwd_bufs[i] = buf
                 recb.append((w1.data_ptr(), w2.data_ptr(), w3.data_ptr(), buf.data_ptr(), int(w1.shape[1]), C))

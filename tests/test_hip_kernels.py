@@ -562,12 +562,16 @@ def test_tap_expanded_zeros_conv_fwd_wgrad(K, N, Cin, C, H, W):
     assert relerr(gw, w.grad) < 1e-4
 
 
-@pytest.mark.parametrize("N,C,Cc,S,act", [(2, 4, 16, 32, 1), (4, 8, 32, 16, 2), (41, 4, 16, 32, 2), (3, 4, 20, 32, 1)])
+@pytest.mark.parametrize("N,C,Cc,S,act", [(2, 4, 16, 32, 1), (4, 8, 32, 16, 2), (41, 4, 16, 32, 2), (3, 4, 20, 32, 1),
+                                          (2, 16, 64, 8, 1), (600, 16, 64, 8, 2), (6, 16, 60, 8, 1),
+                                          (2, 12, 64, 32, 1), (41, 12, 64, 32, 2)])
 def test_coupling_po_fused_forward(K, N, C, Cc, S, act, conv_precision):
     """the fused coupling-net forward (csrc/coupling_po.hip: conv3x3 -> ActNorm -> act -> conv1x1 -> ActNorm -> act ->
     tap-expanded conv3x3, hidden activations handed over in registers, scaled two-piece fp16 arithmetic "f16x3s") against plain fp32
     torch ops on the CPU: h1, h2 and the Conv2dZeros output o = gather(P).  N=41 frames of 32x32 is 328 rounds, more
     than one per persistent workgroup; Cc=20 leaves padded input channels in the last 8-channel group.
+    8x8 maps (level 2 of the canonical flow, Cin 72): two frames per 128-pixel round, 600 frames = 300 rounds, Cc=60 a
+    ragged last channel group; C=12 / Cc=64 on 32x32 maps is level 0 of the BAIR-shaped flow (with_skip conditions).
     Tolerance: 2e-5 of the tensor's largest magnitude (fp32-equivalent arithmetic, different summation order)."""
     if conv_precision != "mixed":
         pytest.skip("the fused kernel is the forward path of the 'mixed' arithmetic")
@@ -603,13 +607,16 @@ def test_coupling_po_fused_forward(K, N, C, Cc, S, act, conv_precision):
     assert relerr(o, orf) < 2e-5
 
 
-@pytest.mark.parametrize("N,C,Cc,S,act", [(2, 4, 16, 32, 1), (4, 8, 32, 16, 2), (41, 4, 16, 32, 1), (3, 8, 32, 16, 1)])
+@pytest.mark.parametrize("N,C,Cc,S,act", [(2, 4, 16, 32, 1), (4, 8, 32, 16, 2), (41, 4, 16, 32, 1), (3, 8, 32, 16, 1),
+                                          (2, 16, 64, 8, 1), (600, 16, 64, 8, 2), (2, 12, 64, 32, 2), (41, 12, 64, 32, 1)])
 def test_coupling_po_fused_backward(K, N, C, Cc, S, act, conv_precision):
     """the fused data-gradient chain of the coupling net (csrc/coupling_po.hip, BWD instantiation: conv3^T -> act' ->
     conv2^T -> act', the intermediate gradient handed over in registers, act' read from the forward kernel's 1-bit masks)
     against torch autograd in fp64 on the CPU: the gradients at the outputs of conv2 and conv1 (ga2, ga1), and the four
     ActNorm gradients that rfn_coupling_po_bwd_finish derives from the per-workgroup sums and the weight gradients
     (gnl[c] = sum_k w[c][k] gw[c][k] + nb[c] gnb[c]).  N=41 frames of 32x32 = 328 rounds: more than one per workgroup.
+    8x8 maps / C=16 is level 2 of the canonical flow (two frames per round, 600 frames = 300 rounds), C=12 on 32x32 maps
+    level 0 of the BAIR-shaped flow (two channel groups of the gradient image).
     Tolerance 2e-5 of the tensor's largest magnitude for the data gradients (f16x3s arithmetic), 1e-4 for the ActNorm
     gradients (they inherit the weight gradients' bf16x3 arithmetic)."""
     if conv_precision != "mixed":
@@ -624,17 +631,6 @@ def test_coupling_po_fused_backward(K, N, C, Cc, S, act, conv_precision):
     n1b, n1l = torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
     n2b, n2l = torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
     go = torch.randn(N, C, S, S, generator=g)
-    actf = (lambda t: F.relu(t)) if act == 1 else (lambda t: F.leaky_relu(t, 0.2))
-    d = lambda t: t.double().clone().requires_grad_(True)
-    w1d, w2d, w3d, n1bd, n1ld, n2bd, n2ld = d(w1), d(w2), d(w3), d(n1b), d(n1l), d(n2b), d(n2l)
-    xin = torch.cat((z[:, :Ch], cond), 1).double()
-    a1 = F.conv2d(xin, w1d, padding=1)
-    a1.retain_grad()
-    h1r = actf((a1 + n1bd.view(1, -1, 1, 1)) * n1ld.exp().view(1, -1, 1, 1))
-    a2 = F.conv2d(h1r, w2d)
-    a2.retain_grad()
-    h2r = actf((a2 + n2bd.view(1, -1, 1, 1)) * n2ld.exp().view(1, -1, 1, 1))
-    F.conv2d(h2r, w3d, padding=1).backward(go.double())
     assert K.coupling_po_ok(N, C, Cc, 256, S, S, w1, w3) and K.coupling_po_bwd_ok(N, C, S, S)
     w1c, w2c, w3c = cu(w1), cu(w2), cu(w3)
     plan = K.POPackPlan([(w1c, w2c, w3c)])
@@ -646,18 +642,34 @@ def test_coupling_po_fused_backward(K, N, C, Cc, S, act, conv_precision):
     ga2, ga1, part = K.coupling_po_bwd(cu(go), plan.bwd_bufs[0], n1lc, n2lc, masks, act)
     torch.cuda.synchronize()
 
-    def check(got, ref, y_ref):
-        """2e-5 of the largest magnitude everywhere -- except where the reference's pre-activation sits within 1e-5 of
-        the activation's kink: there the GPU's own (fp32-grade) forward value may fall on the other side, and act' is
-        discontinuous; such elements must be a vanishing fraction"""
-        e = (got.detach().cpu().double() - ref).abs()
-        bad = e > 2e-5 * float(ref.abs().max())
-        near_kink = y_ref.detach().abs() < 1e-5 * float(y_ref.abs().max())
-        assert not bool((bad & ~near_kink).any()), float(e[bad & ~near_kink].max())
-        assert int(bad.sum()) <= max(2, got.numel() // 1000000)
+    # Reference: fp64 autograd through the same network with the activation's branch (act' = 1 or the negative slope)
+    # taken where the GPU's forward pass took it.  act' is discontinuous at 0, and among 10^7 hidden activations one or two
+    # sit within the forward arithmetic's error of the kink (the forward test's tolerance: 2e-5 of the largest
+    # magnitude); a branch taken the other way changes that element's gradient by a factor and, through conv2^T, all 256
+    # channels of the next gradient at its pixel.  The branches themselves are checked first:
+    # they may differ from the fp64 forward pass only inside that band, and only in a vanishing fraction of elements.
+    slope = 0.0 if act == 1 else 0.2
+    d = lambda t: t.double().clone().requires_grad_(True)
+    w1d, w2d, w3d, n1bd, n1ld, n2bd, n2ld = d(w1), d(w2), d(w3), d(n1b), d(n1l), d(n2b), d(n2l)
+    xin = torch.cat((z[:, :Ch], cond), 1).double()
 
-    check(ga2, a2.grad, a2.detach() + n2bd.detach().view(1, -1, 1, 1))
-    check(ga1, a1.grad, a1.detach() + n1bd.detach().view(1, -1, 1, 1))
+    def act_like_gpu(y, h_gpu):
+        on = h_gpu.detach().cpu() > 0
+        flips = on != (y.detach() > 0)
+        band = 2e-5 * float(y.detach().abs().max())
+        assert int(flips.sum()) <= max(2, y.numel() // 1000000), int(flips.sum())
+        assert not bool((flips & (y.detach().abs() > band)).any())
+        return torch.where(on, y, slope * y)
+
+    a1 = F.conv2d(xin, w1d, padding=1)
+    a1.retain_grad()
+    h1r = act_like_gpu((a1 + n1bd.view(1, -1, 1, 1)) * n1ld.exp().view(1, -1, 1, 1), h1)
+    a2 = F.conv2d(h1r, w2d)
+    a2.retain_grad()
+    h2r = act_like_gpu((a2 + n2bd.view(1, -1, 1, 1)) * n2ld.exp().view(1, -1, 1, 1), h2)
+    F.conv2d(h2r, w3d, padding=1).backward(go.double())
+    assert relerr(ga2, a2.grad) < 2e-5
+    assert relerr(ga1, a1.grad) < 2e-5
     # the weight gradients as the product computes them, then the finishing launch
     gw2 = K.conv2d_wgrad(h1, None, ga2, 256, 1)
     gw1 = K.conv2d_wgrad(cu(z)[:, :Ch], cu(cond), ga1, 256, 3)

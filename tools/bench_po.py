@@ -42,4 +42,6 @@ def run(N, C, Cc, S, reps=10):
 if __name__ == "__main__":
     run(608, 4, 16, 32)
     run(608, 8, 32, 16)
+    run(608, 16, 64, 8)
+    run(76, 12, 64, 32)
 

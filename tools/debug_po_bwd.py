@@ -44,6 +44,13 @@ for rep in range(2):
             print("  cols", sorted(set(idx[:, 3].tolist())))
             i0 = idx[0].tolist()
             print("  first", i0, float(got[tuple(i0)]), float(ref[tuple(i0)]))
+            # the forward values behind the activation mask of the worst element
+            iw = (e == e.max()).nonzero()[0].tolist()
+            hg, hr = (h2, h2r) if name == "ga2" else (h1, h1r)
+            print("  worst", iw, "forward value gpu %.9g  ref %.9g  (max |h| %.4g)" % (
+                float(hg[tuple(iw)]), float(hr[tuple(iw)]), float(hr.abs().max())))
+            fe = (hg.cpu().double() - hr.detach()).abs()
+            print("  forward error: max %.3g at %s" % (float(fe.max()), (fe == fe.max()).nonzero()[0].tolist()))
             # mask disagreement? compare got==0 vs ref==0
             mz = ((got.cpu() == 0) != (ref == 0))
             print("  zero-pattern mismatches", int(mz.sum()))
