@@ -409,11 +409,16 @@ def wgrad_kernel_name(Cout, Cin, ks, HW):
     return "wgrad_mfma_kernel<%d,%s,64>" % (ks, cfg)
 
 
-def _gemm_wgrad_cfg(M, Nc, total):
-    """mirror of the tile choice in rfn_gemm_wgrad_bf16x3 (csrc/wgrad_bf16x3.hip), for profiling labels only"""
+def _gemm_wgrad_name(M, Nc, total, HW=0, ans=0, bns=0):
+    """mirror of the kernel / tile choice in rfn_gemm_wgrad_bf16x3 (csrc/wgrad_bf16x3.hip), for profiling labels only"""
+    if (os.environ.get("RFN_WGRAD_DMA", "1") != "0" and not os.environ.get("RFN_WGRAD_VARIANT") and total >= 100000
+            and HW % 32 == 0 and ans % 4 == 0 and bns % 4 == 0 and Nc > 128 and Nc % 256 == 0 and (M > 128 or M <= 64)):
+        return "gemm_wgrad_dma_kernel<%s>" % ("2,4,4,2,2" if M > 128 else "1,8,2,1,3")
     if M > 128 and Nc > 128 and total >= 100000:
-        return "4,2,2,3,64" if -(-Nc // 192) * 192 < -(-Nc // 256) * 256 else "2,4,4,2,64"
-    return "1,4,2,2,32" if M <= 64 else ("4,1,2,2,32" if Nc <= 64 else "2,2,2,2,64")
+        cfg = "4,2,2,3,64" if -(-Nc // 192) * 192 < -(-Nc // 256) * 256 else "2,4,4,2,64"
+    else:
+        cfg = "1,4,2,2,32" if M <= 64 else ("4,1,2,2,32" if Nc <= 64 else "2,2,2,2,64")
+    return "gemm_wgrad_b3_kernel<%s>" % cfg
 
 
 def gemm_wgrad(a, b, M, Nc, arena=None):
@@ -423,7 +428,7 @@ def gemm_wgrad(a, b, M, Nc, arena=None):
     bp, bns = L.frames(b, "b")
     gw = _zeros(arena, M, Nc, device=a.device)
     L.call("rfn_gemm_wgrad_bf16x3", ap, _l(ans), _i(M), bp, _l(bns), _i(Nc), L.dev(gw), _i(F_), _i(HW),
-           meta=("wgrad", "gemm_wgrad_b3_kernel<%s>" % _gemm_wgrad_cfg(M, Nc, F_ * HW),
+           meta=("wgrad", _gemm_wgrad_name(M, Nc, F_ * HW, HW, ans, bns),
                  2.0 * F_ * HW * M * Nc, "F%d %dx%d HW%d" % (F_, M, Nc, HW), 4.0 * (F_ * HW * (M + Nc) + M * Nc)))
     return gw
 
@@ -475,7 +480,7 @@ def gemm_wgrad_grouped(a_list, b_list, M, Nc, arena=None):
     pa, pb = L.ptr_array(a_list, "a"), L.ptr_array(b_list, "b")
     pg = L.ptr_array([gw[g] for g in range(G)], "gw")
     L.call("rfn_gemm_wgrad_grouped_bf16x3", pa, _l(ans), _i(M), pb, _l(bns), _i(Nc), pg, _i(G), _i(F_), _i(HW),
-           meta=("wgrad", "gemm_wgrad_b3_kernel<grouped %s>" % _gemm_wgrad_cfg(M, Nc, F_ * HW),
+           meta=("wgrad", _gemm_wgrad_name(M, Nc, F_ * HW, 1).replace("<", "<grouped "),
                  2.0 * G * F_ * HW * M * Nc, "G%d F%d %dx%d HW%d" % (G, F_, M, Nc, HW),
                  4.0 * G * (F_ * HW * (M + Nc) + M * Nc)))
     return gw

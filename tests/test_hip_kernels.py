@@ -398,17 +398,24 @@ def test_gauss_logp_fwd_bwd_sample(K, layout, std_mode):
     assert relerr(zs, (mean + std * 0.7 * eps)) < 1e-5
 
 
-@pytest.mark.parametrize("M,Nc,F_,H", [(256, 256, 100, 32), (256, 162, 100, 32), (200, 324, 400, 16), (256, 256, 3, 8)])
-def test_gemm_wgrad_tilings(K, M, Nc, F_, H):
-    """rfn_gemm_wgrad_bf16x3 on the 8-wave 256 x 256 / 256 x 192 tilings (taken for >= 100000 pixels) and the 128 x 128
-    one: gw[m][n] = sum over frames and pixels of a*b, against an fp64 einsum."""
-    if K.CONV_PRECISION != "bf16x3":
+@pytest.mark.parametrize("M,Nc,F_,H,view", [(256, 256, 100, 32, False), (256, 162, 100, 32, False), (200, 324, 400, 16, False),
+                                            (256, 256, 3, 8, False), (256, 256, 131, 32, True), (36, 256, 100, 32, False),
+                                            (72, 256, 401, 16, True), (144, 256, 1700, 8, False)])
+def test_gemm_wgrad_tilings(K, M, Nc, F_, H, view):
+    """rfn_gemm_wgrad_bf16x3: gw[m][n] = sum over frames and pixels of a*b, against an fp64 einsum, on every kernel it
+    selects: the LDS-DMA ring kernel (>= 100000 pixels, HW % 32 == 0, 256-column gradients: 256 x 256 and <= 64 x 256
+    tiles; 131 frames of 32x32 = 4192 stages over 256 workgroups: uneven shares; `view`: operands are channel slices of
+    wider tensors, i.e. frame strides that are not M * HW), the register-staged 8-wave 256 x 192 / 256 x 256 tilings
+    (162 / 324 columns; 144 rows) and the 128 x 128 one."""
+    if not K.bwd_b3():
         pytest.skip("split-precision GEMM only")
     g = torch.Generator().manual_seed(70)
-    a = torch.randn(F_, M, H, H, generator=g)
-    b = torch.randn(F_, Nc, H, H, generator=g)
-    ref = torch.einsum("fmp,fnp->mn", a.flatten(2).double(), b.flatten(2).double())
-    gw = K.gemm_wgrad(cu(a), cu(b), M, Nc)
+    a = torch.randn(F_, M + (8 if view else 0), H, H, generator=g)
+    b = torch.randn(F_, Nc + (4 if view else 0), H, H, generator=g)
+    av, bv = a[:, :M], b[:, 4:] if view else b
+    ref = torch.einsum("fmp,fnp->mn", av.flatten(2).double(), bv.flatten(2).double())
+    ag, bg = cu(a), cu(b)
+    gw = K.gemm_wgrad(ag[:, :M], bg[:, 4:] if view else bg, M, Nc)
     torch.cuda.synchronize()
     assert relerr(gw, ref.float()) < 2e-5
 
