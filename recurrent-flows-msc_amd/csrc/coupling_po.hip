@@ -384,6 +384,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
     // image when its LDS buffer is free, right before converting it: the tensors were written by the launch before this
     // one and come from L2 / the Infinity Cache.
     constexpr bool LATE = RT || (BWD && NG > 1);
+    constexpr bool NOHOIST = LATE || !BWD;   // staging decomposition recomputed every round (registers, see stage_load)
     static_assert((5 * NG) % GS1 == 0 && (!RT || NG % GS1 == 0), "conv1 grouping");
     constexpr int G3 = 2 * NP * GS3;           // fragments per conv3 group
     constexpr int Y1 = 2 * GS1, Y3 = G3 / 4;   // LDS-DMA instructions per wave of a conv1 / conv3 group (conv2: 8)
@@ -457,7 +458,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         // (wide instantiations: the items' decomposition is recomputed every round -- hoisted out of the round loop it is
         // 70+ registers the kernel does not have, i.e. scratch)
         int tid_ = tid;
-        if (LATE) asm volatile("" : "+v"(tid_));
+        if (NOHOIST) asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int it = 0; it < PO_ITEMS; ++it) {
             const int item = tid_ + it * 64 * PO_WAVES;
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
         const int y0_ = FPR > 1 ? 0 : ((rnd & ((1 << RPF_SHIFT) - 1)) * PO_ROUND_PX) >> LOGW;
         float vm = 0.f;
         int tid_ = tid;
-        if (LATE) asm volatile("" : "+v"(tid_));
+        if (NOHOIST) asm volatile("" : "+v"(tid_));
 #pragma unroll
         for (int it = 0; it < PO_ITEMS; ++it) {
             const int item = tid_ + it * 64 * PO_WAVES;
