@@ -384,7 +384,7 @@ __global__ __launch_bounds__(64 * PO_WAVES) void coupling_po_fwd_kernel(const PO
     // image when its LDS buffer is free, right before converting it: the tensors were written by the launch before this
     // one and come from L2 / the Infinity Cache.
     constexpr bool LATE = RT || (BWD && NG > 1);
-    constexpr bool NOHOIST = LATE || !BWD;   // staging decomposition recomputed every round (registers, see stage_load)
+    constexpr bool NOHOIST = LATE || NG == 5;   // staging decomposition recomputed every round (registers, see stage_load)
     static_assert((5 * NG) % GS1 == 0 && (!RT || NG % GS1 == 0), "conv1 grouping");
     constexpr int G3 = 2 * NP * GS3;           // fragments per conv3 group
     constexpr int Y1 = 2 * GS1, Y3 = G3 / 4;   // LDS-DMA instructions per wave of a conv1 / conv3 group (conv2: 8)
