@@ -254,15 +254,21 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
 // operands per launch and sit on the HBM roof -- if the loads are kept in flight.  The register-staged kernel above has
 // ONE stage in flight per workgroup, and only while its MFMAs run: load -> convert -> LDS -> MFMA serialise into
 // ~23 k cycles per 64-pixel stage against ~14 k of pure data movement.  Here the raw fp32 rows go HBM -> LDS by LDS-DMA
-// (global_load_lds_dwordx4, no registers) into a ring of NST stages of 32 pixels, always one or two stages ahead of the
-// MFMAs; the fp32 -> bf16 (hi, lo) split moves to the fragment reads (each wave converts the fragments it consumes:
-// 3x the conversions of the cooperative commit, still below the MFMA time and hidden behind the memory stream).
-//   * one DMA wave-instruction = 1 KB = 8 rows x 128 B (32 pixels of 8 consecutive channels): coalesced 128-B row
-//     segments; LDS image of a stage: [row][8 units of 16 B], row stride 128 B;
-//   * the unit order inside a row is XOR-swizzled with (row >> 1) & 7 -- the LDS destination of a DMA is linear in the
-//     lane, but WHICH global unit a lane fetches is free -- so the fragment reads (lane = row, two ds_read_b128 per
-//     8-pixel fragment) are conflict-free in the hardware's 16-lane groups (MI355X guide, LDS table);
-//   * rows beyond M / N are clamped to the last valid row (their products are never written).
+// (global_load_lds_dwordx4, no registers) into a ring of NST stages of KP pixels, two to three stages ahead of the
+// MFMAs, and the fp32 -> bf16 (hi, lo) split moves to the fragment reads (each wave converts the fragments it consumes:
+// 3x the conversions of a cooperative commit, issued in the shadow of the MFMAs).
+//   * one DMA wave-instruction = 1 KB = 64 / UPR rows x UPR units of 16 B (UPR = KP / 4): coalesced row segments; LDS
+//     image of a stage: [row][UPR units];
+//   * the unit order inside a row is XOR-swizzled with (row / (16 / UPR)) & (UPR - 1) -- the LDS destination of a DMA
+//     is linear in the lane, but WHICH global unit a lane fetches is free -- so the fragment reads (lane = row, two
+//     ds_read_b128 per 8-pixel fragment) are conflict-free in the hardware's 16-lane groups (MI355X guide, LDS table);
+//   * rows beyond M / N are clamped to the last valid row (their products are never written);
+//   * ONE barrier per stage and one continuous software pipeline over all stages: the barrier at the top of stage t
+//     certifies that everybody's pieces of stage t + 1 have landed (its first fragments are read during stage t) and
+//     that everybody has left stage t - 1, whose slot the pieces of stage t + NST - 1 then fill -- issued one at a time
+//     between the MFMAs.  Per unit (k-step, A tile): raw fragment of unit u + 2 read from LDS, TN x 3 MFMAs of unit u,
+//     fragment of unit u + 1 split; the B fragments of the next k-step are read during its unit 0 and split, one tile
+//     per unit, from unit 1 on.
 // K split, epilogue atomics and operand roles are those of gemm_wgrad_b3_kernel (non-implicit, non-grouped).
 template <int N_>
 __device__ __forceinline__ void wg_wait_vm() { asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N_) : "memory"); }
@@ -277,13 +283,23 @@ __device__ __forceinline__ void wg_split8(const f32x4 lo4, const f32x4 hi4, bf16
     }
 }
 
-template <int WM, int WN, int TM, int TN, int NST, int DBG = 0>
+template <int WM, int WN, int TM, int TN, int KP, int NST>
 __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_kernel(const GemmWgradParams p) {
     constexpr int NW = WM * WN;
-    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN, KP = 32;
-    constexpr int ROWS = BM + BN, PIECES = ROWS / 8, PPW = PIECES / NW;   // 1-KB DMA pieces per stage / per wave
-    constexpr int STAGE = ROWS * 128;                                     // bytes per ring slot
-    static_assert(PIECES % NW == 0 && BM % 16 == 0, "DMA pieces are shared evenly; swizzle period divides BM");
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int UPR = KP / 4, RPP = 64 / UPR, SWD = 16 / UPR;          // units per row, rows per piece, swizzle divisor
+    constexpr int RB = KP * 4;                                            // bytes per row and stage
+    constexpr int ROWS = BM + BN, PIECES = ROWS / RPP, PPW = PIECES / NW;  // 1-KB DMA pieces per stage / per wave
+    constexpr int STAGE = ROWS * RB;                                      // bytes per ring slot
+    constexpr int NK = KP / 16, NU_ = NK * TM;                            // k-steps / units per stage
+    static_assert(KP == 16 || KP == 32, "stage width");
+    static_assert(PIECES % NW == 0 && BM % 16 == 0 && NST >= 2, "pieces shared evenly; swizzle period divides BM");
+    // NST >= 3: the software pipeline runs across stage boundaries (the first fragments of stage t + 1 are read during
+    // stage t).  NST == 2 (the 256 x 256 tile: two 64-KB slots of 32 pixels; 16-pixel stages would fit four slots but
+    // their 64-byte row segments stream at half the rate): stage t + 1 is in flight while stage t is consumed, the
+    // pipeline drains and refills at every stage boundary.
+    constexpr bool LOOK = NST >= 3;
+    static_assert(TM % 2 == 0 && TM >= TN + 1, "pipeline parities");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
     const int tid = threadIdx.x, lane = tid & 63;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -299,13 +315,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_kernel(const Gemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
-    // this lane's share of a stage: PPW pieces; piece q = wave + j NW covers stacked rows 8q .. 8q+7 (A rows, then B rows)
+    // this lane's share of a stage: PPW pieces; piece q = wave + j NW covers stacked rows RPP q .. (A rows, then B rows)
     const float* prow[PPW];   // row base + this lane's (swizzled) unit
     bool pisa[PPW];
 #pragma unroll
     for (int j = 0; j < PPW; ++j) {
-        const int r = 8 * (wave + j * NW) + (lane >> 3);          // stacked row
-        const int u = (lane & 7) ^ ((r >> 1) & 7);                // global unit that lands in LDS unit (lane & 7)
+        const int r = RPP * (wave + j * NW) + lane / UPR;               // stacked row
+        const int u = (lane & (UPR - 1)) ^ ((r / SWD) & (UPR - 1));     // global unit that lands in LDS unit lane % UPR
         pisa[j] = r < BM;
         if (pisa[j]) {
             int row = m0 + r;
@@ -318,107 +334,138 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_kernel(const Gemm
         }
     }
     const unsigned uHW = (unsigned)p.HW;
-    auto issue = [&](const int stage, const int slot) {
-        const unsigned q0 = (unsigned)stage * KP;
-        const unsigned f = q0 / uHW, px = q0 - f * uHW;          // a stage never straddles a frame (HW % 32 == 0)
-        const long offa = (long)f * p.a_ns + px, offb = (long)f * p.b_ns + px;
-        unsigned char* dst = lds_raw + slot * STAGE + wave * 1024;
-#pragma unroll
-        for (int j = 0; j < PPW; ++j)
-            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(prow[j] + (pisa[j] ? offa : offb)),
-                                             (__attribute__((address_space(3))) void*)(dst + j * NW * 1024), 16, 0, 0);
+    const int S = gridDim.x;
+    const int nmine = (p.n_stages - (int)blockIdx.x + S - 1) / S;   // my stages: blockIdx.x, + S, ...
+    // frame / pixel offsets of my stage t (clamped to my last one: pieces past the end re-read it and are never used)
+    long offa = 0, offb = 0;
+    auto stage_offsets = [&](int t) {
+        t = t < nmine ? t : nmine - 1;
+        const unsigned q0 = (unsigned)(blockIdx.x + t * S) * KP;
+        const unsigned f = q0 / uHW, px = q0 - f * uHW;          // a stage never straddles a frame (HW % KP == 0)
+        offa = (long)f * p.a_ns + px;
+        offb = (long)f * p.b_ns + px;
+    };
+    auto piece = [&](const int j, const int slot) {
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(prow[j] + (pisa[j] ? offa : offb)),
+                                         (__attribute__((address_space(3))) void*)(lds_raw + slot * STAGE + (wave + j * NW) * 1024),
+                                         16, 0, 0);
     };
 
-    // fragment addresses inside a slot: row * 128 + ((2 (2 s + kk) + h) ^ swz(row)) * 16,  swz = (row >> 1) & 7
+    // fragment byte offsets inside a slot: row * RB + ((2 (2 s + kk) + h) ^ swz(row)) * 16
     int aoff[TM], boff[TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
         const int r = (wm * TM + i) * 32 + l31;
-        aoff[i] = r * 128 + (((2 * kk) ^ ((r >> 1) & 7)) << 4);
+        aoff[i] = r * RB + (((2 * kk) ^ ((r / SWD) & (UPR - 1))) << 4);
     }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int r = BM + (wn * TN + j) * 32 + l31;
-        boff[j] = r * 128 + (((2 * kk) ^ ((r >> 1) & 7)) << 4);
+        boff[j] = r * RB + (((2 * kk) ^ ((r / SWD) & (UPR - 1))) << 4);
     }
+    auto raw = [&](const unsigned char* sb, const int off, const int s_, f32x4 (&r)[2]) {
+        const int o = off ^ (s_ << 6);
+        r[0] = *reinterpret_cast<const f32x4*>(sb + o);
+        r[1] = *reinterpret_cast<const f32x4*>(sb + (o ^ 16));
+    };
 
-    const int S = gridDim.x;
-    const int nmine = (p.n_stages - (int)blockIdx.x + S - 1) / S;   // stages blockIdx.x, + S, ...
+    // prologue: stages 0 .. NST-2 in flight; (LOOK) stage 0 landed, its first fragments read and split
 #pragma unroll
-    for (int t = 0; t < NST; ++t)
-        if (t < nmine) issue(blockIdx.x + t * S, t);
-    int slot = 0;
-    for (int it = 0; it < nmine; ++it) {
-        // my pieces of this stage have landed once at most (stages issued after it) x PPW of my DMAs are outstanding
-        const int younger = nmine - 1 - it < NST - 1 ? nmine - 1 - it : NST - 1;
-        if (younger >= 2) wg_wait_vm<2 * PPW>();
-        else if (younger == 1) wg_wait_vm<PPW>();
-        else wg_wait_vm<0>();
-        __builtin_amdgcn_s_barrier();
-        const unsigned char* sb = lds_raw + slot * STAGE;
-        if (DBG != 1) {
-        // Software pipeline over the stage's units (k-step s, A tile i): while the MFMAs of unit u run (TN x 3 of them),
-        // the raw fragment of unit u + 2 is read from LDS and the one of unit u + 1 is split into (hi, lo) -- the
-        // conversions (3 VALU per value) fit into the issue slots the MFMAs leave free.  The B fragments of k-step s + 1
-        // are read during unit (s, 0) and converted, one tile per unit, from unit (s, 1) on.
-        constexpr int NU_ = (KP / 16) * TM;
-        static_assert(TM >= TN + 1, "B tiles of the next k-step are converted during units 1 .. TN of this one");
-        auto rawA = [&](const int u, f32x4 (&r)[2]) {
-            const int o = aoff[u % TM] ^ ((u / TM) << 6);
-            r[0] = *reinterpret_cast<const f32x4*>(sb + o);
-            r[1] = *reinterpret_cast<const f32x4*>(sb + (o ^ 16));
-        };
-        auto rawB = [&](const int s_, const int j, f32x4 (&r)[2]) {
-            const int o = boff[j] ^ (s_ << 6);
-            r[0] = *reinterpret_cast<const f32x4*>(sb + o);
-            r[1] = *reinterpret_cast<const f32x4*>(sb + (o ^ 16));
-        };
-        f32x4 ra[2][2], rb[TN][2];
-        bf16x8 ah[2], al[2], bh[2][TN], bl[2][TN];
+    for (int t = 0; t < NST - 1; ++t) {
+        stage_offsets(t);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) rawB(0, j, rb[j]);
-        rawA(0, ra[0]);
-        rawA(1, ra[1]);
+        for (int j = 0; j < PPW; ++j) piece(j, t);
+    }
+    f32x4 ra[2][2], rb[TN][2];
+    bf16x8 ah[2], al[2], bh[2][TN], bl[2][TN];
+    auto first_fragments = [&](const unsigned char* sb0) {
+#pragma unroll
+        for (int j = 0; j < TN; ++j) raw(sb0, boff[j], 0, rb[j]);
+        raw(sb0, aoff[0], 0, ra[0]);
+        raw(sb0, aoff[1], 0, ra[1]);
 #pragma unroll
         for (int j = 0; j < TN; ++j) wg_split8(rb[j][0], rb[j][1], bh[0][j], bl[0][j]);
         wg_split8(ra[0][0], ra[0][1], ah[0], al[0]);
+    };
+    if (LOOK) {
+        wg_wait_vm<(NST - 2) * PPW>();
+        __builtin_amdgcn_s_barrier();
+        first_fragments(lds_raw);
+    }
+
+    int slot = 0;
+    for (int it = 0; it < nmine; ++it) {
+        // top of stage `it`.  LOOK: my pieces of stage it + 1 have landed once only those of the stages issued after it
+        // are outstanding; the barrier makes that everybody's pieces and frees the slot of stage it - 1.  Two slots: the
+        // same for stage `it` itself (nothing younger is outstanding).
+        wg_wait_vm<LOOK ? (NST - 3) * PPW : 0>();
+        __builtin_amdgcn_s_barrier();
+        const int nslot = slot + 1 == NST ? 0 : slot + 1;
+        const int fslot = slot == 0 ? NST - 1 : slot - 1;          // slot of stage it - 1 = slot of stage it + NST - 1
+        const unsigned char* sb = lds_raw + slot * STAGE;
+        const unsigned char* sn = lds_raw + nslot * STAGE;
+        stage_offsets(it + NST - 1);
+        if (!LOOK) {
+            // two slots: the next stage's pieces have exactly this stage to land -- issued before anything else
+#pragma unroll
+            for (int j = 0; j < PPW; ++j) piece(j, fslot);
+            first_fragments(sb);
+        }
 #pragma unroll
         for (int u = 0; u < NU_; ++u) {
-            const int s_ = u / TM, i = u % TM, cur = u & 1, sb_ = s_ & 1;
-            if (u + 2 < NU_) rawA(u + 2, ra[cur]);                       // (ra[cur] was consumed when unit u was converted)
-            if (i == 0 && s_ + 1 < KP / 16) {
+            const int s_ = u / TM, i = u % TM, cur = u & 1, kb = s_ & 1;
+            // raw A fragment of unit u + 2 (this stage or the next one)
+            if (u + 2 < NU_) raw(sb, aoff[(u + 2) % TM], (u + 2) / TM, ra[cur]);
+            else if (LOOK) raw(sn, aoff[(u + 2) % TM], 0, ra[cur]);
+            // raw B fragments of the next k-step
+            if (i == 0) {
 #pragma unroll
-                for (int j = 0; j < TN; ++j) rawB(s_ + 1, j, rb[j]);
+                for (int j = 0; j < TN; ++j) {
+                    if (s_ + 1 < NK) raw(sb, boff[j], s_ + 1, rb[j]);
+                    else if (LOOK) raw(sn, boff[j], 0, rb[j]);
+                }
+            }
+            // the DMA pieces of the stage that will fill the freed slot (NST - 2 stages to land): one per MFMA gap of
+            // the first unit(s)
+            if (LOOK && u == 0) {
+#pragma unroll
+                for (int j = 0; j < PPW; ++j) piece(j, fslot);
             }
 #pragma unroll
             for (int j = 0; j < TN; ++j) {
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[sb_][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[sb_][j], acc[i][j], 0, 0, 0);
-                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[sb_][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur], bh[kb][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bl[kb][j], acc[i][j], 0, 0, 0);
+                acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur], bh[kb][j], acc[i][j], 0, 0, 0);
             }
-            if (u + 1 < NU_) wg_split8(ra[cur ^ 1][0], ra[cur ^ 1][1], ah[cur ^ 1], al[cur ^ 1]);
-            if (i >= 1 && i <= TN && s_ + 1 < KP / 16)
-                wg_split8(rb[i - 1][0], rb[i - 1][1], bh[sb_ ^ 1][i - 1], bl[sb_ ^ 1][i - 1]);
+            if (LOOK || u + 1 < NU_) wg_split8(ra[cur ^ 1][0], ra[cur ^ 1][1], ah[cur ^ 1], al[cur ^ 1]);
+            if (i >= 1 && i <= TN && (LOOK || s_ + 1 < NK))
+                wg_split8(rb[i - 1][0], rb[i - 1][1], bh[kb ^ 1][i - 1], bl[kb ^ 1][i - 1]);
         }
-        // the schedule of the block above, spelled out for the compiler (left alone it issues the conversions in long
-        // VALU runs and the MFMAs back to back, i.e. one after the other): LDS reads and conversions of the first
-        // fragments, then after every MFMA up to six VALU and one LDS read in its shadow
-        __builtin_amdgcn_sched_group_barrier(0x100, 2 * TN + 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 30 * (TN + 1), 0);
+        if (LOOK && (NK & 1)) {   // an odd number of k-steps per stage: the next stage starts on the other B buffer
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[0][j] = bh[1][j];
+                bl[0][j] = bl[1][j];
+            }
+        }
+        // the schedule of the stage, spelled out for the compiler (left alone it issues the conversions in long VALU
+        // runs and the MFMAs back to back, i.e. one after the other): after every MFMA up to six VALU, one LDS read
+        // and (first units) one DMA piece in its shadow
+        if (!LOOK) {
+            __builtin_amdgcn_sched_group_barrier(0x020, PPW, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 2 * TN + 4, 0);
+            __builtin_amdgcn_sched_group_barrier(0x002, 30 * (TN + 1), 0);
+        }
 #pragma unroll
         for (int g = 0; g < NU_ * TN * 3; ++g) {
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
             __builtin_amdgcn_sched_group_barrier(0x002, 6, 0);
             __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+            if (LOOK && g < PPW) __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
         }
-        }
-        if (it + NST < nmine) {
-            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-            __builtin_amdgcn_s_barrier();   // every wave has read this slot: refill it
-            if (DBG != 2) issue(blockIdx.x + (it + NST) * S, slot);
-        }
-        slot = slot + 1 == NST ? 0 : slot + 1;
+        slot = nslot;
     }
+    wg_wait_vm<0>();   // (pieces past the end)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -432,18 +479,16 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_kernel(const Gemm
         }
 }
 
-template <int WM, int WN, int TM, int TN, int NST>
+template <int WM, int WN, int TM, int TN, int KP, int NST>
 static void launch_gemm_wgrad_dma(GemmWgradParams& p, hipStream_t s) {
     constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
-    p.n_stages = (int)(p.total / 32);
-    const size_t lds = (size_t)NST * (BM + BN) * 128;
+    p.n_stages = (int)(p.total / KP);
+    const size_t lds = (size_t)NST * (BM + BN) * KP * 4;
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
     int S = 256 / tiles;   // one 8-wave workgroup per CU (see launch_gemm_wgrad)
     if (S > p.n_stages / 8) S = p.n_stages / 8;
     if (S < 1) S = 1;
-    static const int dbg = getenv("RFN_WGRAD_DBG") ? atoi(getenv("RFN_WGRAD_DBG")) : 0;
-    auto kern = dbg == 1 ? gemm_wgrad_dma_kernel<WM, WN, TM, TN, NST, 1>
-              : dbg == 2 ? gemm_wgrad_dma_kernel<WM, WN, TM, TN, NST, 2> : gemm_wgrad_dma_kernel<WM, WN, TM, TN, NST>;
+    auto kern = gemm_wgrad_dma_kernel<WM, WN, TM, TN, KP, NST>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
@@ -480,8 +525,8 @@ static void select_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
     const int M = p.M, Nc = p.N;
     static const int variant = getenv("RFN_WGRAD_VARIANT") ? atoi(getenv("RFN_WGRAD_VARIANT")) : 0;
     if (variant == 0 && wgrad_dma_ok(p)) {
-        if (M > 128 && Nc % 256 == 0) return launch_gemm_wgrad_dma<2, 4, 4, 2, 2>(p, s);   // 256 x 256, ring of 2 x 64 KB
-        if (M <= 64 && Nc % 256 == 0) return launch_gemm_wgrad_dma<1, 8, 2, 1, 3>(p, s);   // 64 x 256, ring of 3 x 40 KB
+        if (M > 128 && Nc % 256 == 0) return launch_gemm_wgrad_dma<2, 4, 4, 2, 32, 2>(p, s);   // 256 x 256, two slots of 64 KB
+        if (M <= 64 && Nc % 256 == 0) return launch_gemm_wgrad_dma<1, 8, 2, 1, 32, 3>(p, s);   // 64 x 256, ring of 3 x 40 KB
     }
     const bool big = variant != 1 && M > 128 && Nc > 128 && p.total >= 100000;
     if (big && ceil_div(Nc, 192) * 192 < ceil_div(Nc, 256) * 256) {
