@@ -145,7 +145,11 @@ int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_st
  * the backward pass needs them).  Arithmetic "f16x3s": every operand is scaled by a power of two (per tensor for
  * weights, per block for the staged input, per pixel for the hidden activations) and split into two fp16 pieces
  * (22 significant bits); a product is three v_mfma_f32_32x32x16_f16 with fp32 accumulation, the scale undone in fp32.
- *   rfn_coupling_po_supported  1 when (N, C, Cc, Hd, H, W) is a shape the kernel takes (else use the unfused kernels);
+ *   rfn_coupling_po_supported  1 when (N, C, Cc, Hd, H, W) is a shape the kernel takes (else use the unfused kernels):
+ *       Hd = 256, square power-of-two maps, N*H*W a multiple of 128 (a workgroup round is 128 consecutive pixels of the
+ *       (frame, pixel) sequence: rows of one frame, or two whole 8x8 frames) and one of the instantiated channel-group
+ *       counts (NG = ceil((C/2 + Cc) / 8), NP = ceil(9C / 32), W): (3, 2, 32) and (5, 3, 16) = levels 0 / 1 of the
+ *       canonical flow, (9, 5, 8) = its level 2, (9, 4, 32) = a C = 12 flow with 59..66 condition channels;
  *   rfn_coupling_po_packed_bytes / rfn_coupling_po_pack  the fragment-ordered weight stream of one coupling net
  *       (descs_device: device array of n rfn_po_pack_desc; one launch packs every net of a flow);
  *   rfn_coupling_po_fwd  z: output of ActNorm+InvConv [N, >=C/2, H, W] (channels [0, C/2) are read), cond [N, Cc, H, W];
@@ -156,7 +160,8 @@ int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_st
  *       register) order -- act'(.) for rfn_coupling_po_bwd, 1/32 of the activations' bytes.
  * Backward of the same three convolutions' DATA path (backward of glow_modules.py:232-238), one kernel:
  *   rfn_coupling_po_bwd_supported / rfn_coupling_po_bwd_packed_bytes / rfn_coupling_po_pack_bwd  as above for the
- *       backward stream (w3 transposed + mirrored, w2 transposed; descs: w2, w3, dst, C are read);
+ *       backward stream (w3 transposed + mirrored, w2 transposed; descs: w2, w3, dst, C are read); gradient images of
+ *       C <= 8 channels on 32x32 / 16x16 maps and of 9..16 channels on 8x8 / 32x32 maps;
  *   rfn_coupling_po_bwd  go [N, C, H, W] = gradient at conv3's output ->
  *       ga2 = (conv3^T go) act'(h2) exp(n2l), ga1 = (w2^T ga2) act'(h1) exp(n1l)  [N, 256, H, W] each (the gradients at
  *       the outputs of conv2 / conv1: operands of the weight gradients and of conv1's data gradient), and
@@ -249,7 +254,11 @@ int rfn_conv3x3_smallcout_bf16x3(const float* in, long in_ns, int Cin, const flo
 /* Split-precision weight-gradient GEMM: gw[M][Nc] += Σ_{f,p} a[f][m][p] * b[f][n][p]  (a: [F,M,HW] frame stride a_ns,
  * b: [F,Nc,HW] frame stride b_ns; HW % 4 == 0, 16-byte aligned bases).  gw is accumulated with float atomics (caller
  * zeroes it).  1x1 weight gradients use it directly (a = output grad, b = conv input); 3x3 ones first expand the
- * smaller operand: b = rfn_im2col3x3_f32(input) [9*Cin rows, tap-major] or a = rfn_tap_scatter_f32(grad) [9*Cout rows]. */
+ * smaller operand: b = rfn_im2col3x3_f32(input) [9*Cin rows, tap-major] or a = rfn_tap_scatter_f32(grad) [9*Cout rows].
+ * Kernel choice (same arithmetic, same result up to summation order): F*HW >= 100000 pixels, HW % 32 == 0 and
+ * Nc % 256 == 0 with M > 128 or M <= 64 -> the LDS-DMA ring kernel (raw fp32 rows HBM -> LDS by global_load_lds, split
+ * at the fragment reads; RFN_WGRAD_DMA=0 disables it); otherwise the register-staged tilings (RFN_WGRAD_VARIANT,
+ * RFN_WGRAD_SPLIT: tile / K-split experiments). */
 int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw, int F, int HW,
                           rfn_stream_t stream);
 /* G (<= 16) gradients of ONE shape in one launch (the K steps of a flow level, where a single gradient is a

@@ -20,5 +20,7 @@ cd /tmp
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_f -o f -- python3 $GRAFT_REPO_ROOT/bench.py --child --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --secondary --no-parity > $GRAFT_REPO_ROOT/gpurun_out/pmc_f.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_w -o w -- python3 $GRAFT_REPO_ROOT/bench.py --child --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --secondary --no-parity > $GRAFT_REPO_ROOT/gpurun_out/pmc_w.log 2>&1
 cd $GRAFT_REPO_ROOT
-python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w gemm_wgrad_b3_kernel gpurun_out/pmc_dominant_traffic.json
+DOM=$(python -c "import json; print(json.loads(open('gpurun_out/b.json').read().strip().splitlines()[-1])['roofline']['kernel'])")
+echo "dominant kernel template: $DOM"
+python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w "$DOM" gpurun_out/pmc_dominant_traffic.json
 rm -f gpurun_out/pmc_f/*/*counter_collection.csv gpurun_out/pmc_w/*/*counter_collection.csv

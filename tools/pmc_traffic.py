@@ -7,13 +7,21 @@ def sha16(rel):
     return hashlib.sha256(open(os.path.join(ROOT, rel), "rb").read()).hexdigest()[:16]
 # the source file of each kernel whose traffic has been measured: bench.py drops the figure when the source changed
 KERNEL_SOURCE = {"coupling_po_fwd_kernel": "recurrent-flows-msc_amd/csrc/coupling_po.hip",
-                 "coupling_po_bwd": "recurrent-flows-msc_amd/csrc/coupling_po.hip",
+                 "coupling_po_bwd_kernel": "recurrent-flows-msc_amd/csrc/coupling_po.hip",
                  "gemm_wgrad_b3_kernel": "recurrent-flows-msc_amd/csrc/wgrad_bf16x3.hip",
+                 "gemm_wgrad_dma_kernel": "recurrent-flows-msc_amd/csrc/wgrad_bf16x3.hip",
                  "conv1x1_ws_kernel": "recurrent-flows-msc_amd/csrc/conv_bf16x3.hip"}
+def matches(sym, name):
+    """the bench labels the two instantiation families of coupling_po_fwd_kernel<..., BWD> as two kernels"""
+    if sym == "coupling_po_fwd_kernel":
+        return "coupling_po_fwd_kernel" in name and "false>" in name
+    if sym == "coupling_po_bwd_kernel":
+        return "coupling_po_fwd_kernel" in name and "true>" in name
+    return sym in name
 def mean_kb(d, counter, sym):
     f = (glob.glob(d + "/*/*counter_collection.csv") + glob.glob(d + "/*counter_collection.csv"))[0]
     vals = [float(r["Counter_Value"]) for r in csv.DictReader(open(f))
-            if r["Counter_Name"] == counter and sym in r["Kernel_Name"]]
+            if r["Counter_Name"] == counter and matches(sym, r["Kernel_Name"])]
     return sum(vals) / len(vals), len(vals)
 fetch, n1 = mean_kb(sys.argv[1], "FETCH_SIZE", sys.argv[3])
 write, n2 = mean_kb(sys.argv[2], "WRITE_SIZE", sys.argv[3])
