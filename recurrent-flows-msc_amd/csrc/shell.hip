@@ -342,18 +342,32 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
             if (grp < G_) {
                 const float* gi = G + (e / C) * PBS;
                 const float* yj = Y + (e % C) * PBS;
-                float a = 0.f;
-                for (int pp = grp + G_ * blockIdx.y; pp < PB; pp += G_ * gridDim.y) a = fmaf(gi[pp], yj[pp], a);
-                atomicAdd(&Wacc[e], a);
+                // (four independent partial sums: the LDS reads of four pixels are in flight instead of one)
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+                const int st = G_ * gridDim.y;
+                int pp = grp + G_ * blockIdx.y;
+                for (; pp + 3 * st < PB; pp += 4 * st) {
+                    a0 = fmaf(gi[pp], yj[pp], a0);
+                    a1 = fmaf(gi[pp + st], yj[pp + st], a1);
+                    a2 = fmaf(gi[pp + 2 * st], yj[pp + 2 * st], a2);
+                    a3 = fmaf(gi[pp + 3 * st], yj[pp + 3 * st], a3);
+                }
+                for (; pp < PB; pp += st) a0 = fmaf(gi[pp], yj[pp], a0);
+                atomicAdd(&Wacc[e], (a0 + a1) + (a2 + a3));
             }
         } else {
             // entries are split over blockIdx.y (deep levels have few pixel tiles: 38 at the 2x2 level)
             for (int e = blockIdx.y * 256 + t; e < E; e += 256 * gridDim.y) {
                 const float* gi = G + (e / C) * PBS;
                 const float* yj = Y + (e % C) * PBS;
-                float a = 0.f;
-                for (int pp = 0; pp < PB; ++pp) a = fmaf(gi[pp], yj[pp], a);
-                Wacc[e] += a;
+                float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;   // (PB is a multiple of 4)
+                for (int pp = 0; pp < PB; pp += 4) {
+                    a0 = fmaf(gi[pp], yj[pp], a0);
+                    a1 = fmaf(gi[pp + 1], yj[pp + 1], a1);
+                    a2 = fmaf(gi[pp + 2], yj[pp + 2], a2);
+                    a3 = fmaf(gi[pp + 3], yj[pp + 3], a3);
+                }
+                Wacc[e] += (a0 + a1) + (a2 + a3);
             }
         }
         // gy_j = Σ_i W[i][j] gz_i ; gx_j = gy_j * exp(logs_j) ; gbias_j += Σ gx_j ; glogs_j += Σ gy_j y_j.
@@ -379,7 +393,25 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
             }
         } else {
             const int Ch = C >> 1;
-            for (int j = cg + ncg * blockIdx.y; j < Ch; j += ncg * gridDim.y) {
+            // the coupling backward's global operands (o[2j], o[2j+1], x[j+Ch] of this pixel) are loaded one channel
+            // pair AHEAD of the matrix-vector product that needs them: used right after their load they cost one
+            // global-memory latency per pair (4 pairs per thread at C = 16: 8 of the launch's 30 us)
+            const int j0 = cg + ncg * blockIdx.y, jst = ncg * gridDim.y;
+            const float gld = (valid && tl.glogdet) ? tl.glogdet[n] : 0.f;
+            const float* op = tl.o + n * tl.o_ns + p;
+            float o0n = 0.f, svn = 0.f, zon = 0.f;
+            if (valid && j0 < Ch) {
+                o0n = op[(long)(2 * j0) * HW];
+                svn = op[(long)(2 * j0 + 1) * HW];
+                zon = xs[(long)(j0 + Ch) * HW];
+            }
+            for (int j = j0; j < Ch; j += jst) {
+                const float o0 = o0n, sv = svn, zo = zon;
+                if (valid && j + jst < Ch) {
+                    o0n = op[(long)(2 * (j + jst)) * HW];
+                    svn = op[(long)(2 * (j + jst) + 1) * HW];
+                    zon = xs[(long)(j + jst + Ch) * HW];
+                }
                 float a1 = 0.f, a2 = 0.f;
 #pragma unroll 8
                 for (int i = 0; i < C; ++i) {
@@ -389,13 +421,6 @@ __global__ __launch_bounds__(256) void actnorm_invconv_bwd_kernel(
                 }
                 const float g1 = a1 * expf(logs[j]), g2 = a2 * expf(logs[j + Ch]);  // previous step's gout at (j, j+Ch)
                 // previous step: z2' = (z2 + o[2j]) * exp(ls(o[2j+1])), its output z2' is this step's x at channel j+Ch
-                float o0 = 0.f, sv = 0.f, zo = 0.f, gld = 0.f;
-                if (valid) {
-                    o0 = tl.o[n * tl.o_ns + (long)(2 * j) * HW + p];
-                    sv = tl.o[n * tl.o_ns + (long)(2 * j + 1) * HW + p];
-                    zo = xs[(long)(j + Ch) * HW];
-                    if (tl.glogdet) gld = tl.glogdet[n];
-                }
                 float sc = 0.f, sh = 0.f;
                 if (tl.clamp_type == 0) {
                     sc = tl.scale[j];
@@ -913,6 +938,7 @@ struct ShellFwdParams {
     int ld_slots;  // frames a block can touch: (PB - 1) / HW + 2
 };
 
+struct __attribute__((aligned(16))) f32x4_s { float x, y, z, w; };
 __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParams q_) {
     extern __shared__ float lds[];  // head: [C][PB]
     __shared__ float red[256];      // log-det shares of the block's threads
@@ -1029,6 +1055,50 @@ __global__ __launch_bounds__(256) void glow_shell_fwd_kernel(const ShellFwdParam
         }
     }
     if (!a.head) return;
+    if (C >= 16 && C % NG == 0 && (C / NG) % 2 == 0) {
+        // deep levels: the C x C matrix goes through LDS, transposed (Wt[j][i]); a thread forms OPT = C / NG CONSECUTIVE
+        // outputs, four (or two) at a time: per input channel one read of y and one broadcast read of the weights.  (Read
+        // from global memory per (i, j) -- with PB = 32 a wave spans two channel groups, so not even through the scalar
+        // cache -- the 64 x 64 product of the 2x2 level was 12 of the launch's 18 us.)
+        float* Wt = lds + C * PB;
+        for (int e = threadIdx.x; e < C * C; e += 256) Wt[e] = a.Wm[(e % C) * C + e / C];   // Wt[j][i] = W[i][j]
+        __syncthreads();
+        if (valid) {
+            float* dst = a.znext + n * a.znext_ns + p;
+            const int OPT = C / NG;
+            if (OPT % 4 == 0 && C % 4 == 0) {
+                for (int k0 = 0; k0 < OPT; k0 += 4) {
+                    const int i0 = ig * OPT + k0;
+                    float acc[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll 4
+                    for (int j = 0; j < C; ++j) {
+                        const float yv = lds[j * PB + px];
+                        const f32x4_s w4 = *reinterpret_cast<const f32x4_s*>(Wt + j * C + i0);
+                        acc[0] = fmaf(w4.x, yv, acc[0]);
+                        acc[1] = fmaf(w4.y, yv, acc[1]);
+                        acc[2] = fmaf(w4.z, yv, acc[2]);
+                        acc[3] = fmaf(w4.w, yv, acc[3]);
+                    }
+#pragma unroll
+                    for (int k = 0; k < 4; ++k) dst[(long)(i0 + k) * HW] = acc[k];
+                }
+            } else {
+                for (int k0 = 0; k0 < OPT; k0 += 2) {
+                    const int i0 = ig * OPT + k0;
+                    float acc0 = 0.f, acc1 = 0.f;
+#pragma unroll 4
+                    for (int j = 0; j < C; ++j) {
+                        const float yv = lds[j * PB + px];
+                        acc0 = fmaf(Wt[j * C + i0], yv, acc0);
+                        acc1 = fmaf(Wt[j * C + i0 + 1], yv, acc1);
+                    }
+                    dst[(long)i0 * HW] = acc0;
+                    dst[(long)(i0 + 1) * HW] = acc1;
+                }
+            }
+        }
+        return;
+    }
     __syncthreads();
     if (valid) {
         float* dst = a.znext + n * a.znext_ns + p;
@@ -1099,7 +1169,7 @@ extern "C" int rfn_glow_shell_fwd_f32(float* z, long z_ns, const float* P, const
     const int HW = H * W;
     const int PB = shell_fwd_pb(N, C, HW);
     const long tot = (long)N * HW;
-    size_t lds = head ? (size_t)C * PB * 4 : 0;
+    size_t lds = head ? (size_t)C * PB * 4 + (C >= 16 ? (size_t)C * C * 4 : 0) : 0;
     if (lds > 160 * 1024) {
         rfn_set_error("glow_shell_fwd: C=%d too large for the LDS-staged kernel", C);
         return -6;
