@@ -494,6 +494,215 @@ static void launch_gemm_wgrad_dma(GemmWgradParams& p, hipStream_t s) {
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
 }
 
+// Implicit 3x3 form of the ring kernel (conv1's weight gradient at the shallow levels: gw[256][ci*9 + tap], A = the
+// 256-channel gradient image, B = the 18 / 36 input planes shifted by the tap).  The BIG operand A goes through the DMA
+// ring (two slots of 256 rows x 32 pixels, split at the fragment reads) exactly as above; the SMALL operand keeps the
+// cooperative register staging of gemm_wgrad_b3_kernel<..., IMPL = 1> -- its 9 Cin rows are built from L2-resident
+// planes with the shift and the (hi, lo) split, into a double buffer of bf16 planes: the loads of stage t + 1 are issued
+// at the top of stage t, committed at its end (which also certifies that the DMA pieces issued before them have landed:
+// vector-memory operations complete in order), and the barrier at the top of stage t + 1 publishes both.
+template <int WM, int WN, int TM, int TN>
+__global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_impl_kernel(const GemmWgradParams p) {
+    constexpr int NW = WM * WN, NT = 64 * NW, KP = 32, NK = KP / 16;
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    constexpr int PIECES = BM / 8, PPW = PIECES / NW;   // 1-KB DMA pieces (8 rows x 128 B) of the A rows per stage / wave
+    constexpr int ASLOT = BM * 128;
+    constexpr int NU = KP / 8, RS = NU + 1;             // B planes: 16-byte units per row, row stride (conflict-free)
+    constexpr int BU = (BN * NU + NT - 1) / NT;         // B units staged per thread
+    constexpr int BPLANE = BN * RS;                     // units per plane
+    static_assert(PIECES % NW == 0 && NT % NU == 0 && TM % 2 == 0, "shares / parities");
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+    bf16x8* const Bbase = reinterpret_cast<bf16x8*>(lds_raw + 2 * ASLOT);   // [buffer 2][plane 2][BN][RS]
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wm = wave / WN, wn = wave % WN;
+    const int l31 = lane & 31, kk = lane >> 5;
+    const int m0 = blockIdx.z * BM, n0 = blockIdx.y * BN;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+    // ---- A: DMA pieces of this lane (rows 8 q .. 8 q + 7 of the tile, swizzled units: see gemm_wgrad_dma_kernel)
+    const float* prow[PPW];
+#pragma unroll
+    for (int j = 0; j < PPW; ++j) {
+        const int r = 8 * (wave + j * NW) + (lane >> 3);
+        const int u = (lane & 7) ^ ((r >> 1) & 7);
+        int row = m0 + r;
+        row = row < p.M ? row : p.M - 1;
+        prow[j] = p.a + (long)row * p.HW + 4 * u;
+    }
+    int aoff[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int r = (wm * TM + i) * 32 + l31;
+        aoff[i] = r * 128 + (((2 * kk) ^ ((r >> 1) & 7)) << 4);
+    }
+    // ---- B: this thread's units (fixed row n = ci * 9 + tap, k-group kg): plane, frame stride, tap
+    const int kg = tid % NU, r0 = tid / NU;
+    const float* uplane[BU];
+    long uns[BU];
+    int udy[BU], udx[BU];
+#pragma unroll
+    for (int u = 0; u < BU; ++u) {
+        int row = n0 + r0 + u * (NT / NU);
+        if (row >= p.N) row = 0;
+        const int ci = row / 9, tap = row - ci * 9;
+        udy[u] = tap / 3 - 1;
+        udx[u] = tap % 3 - 1;
+        const bool first = ci < p.C1;
+        uplane[u] = first ? p.b + (long)ci * p.HW : p.b2 + (long)(ci - p.C1) * p.HW;
+        uns[u] = first ? p.b_ns : p.b2_ns;
+    }
+    const unsigned uHW = (unsigned)p.HW;
+    const int S = gridDim.x;
+    const int nmine = (p.n_stages - (int)blockIdx.x + S - 1) / S;
+    float4 bst[BU][2];
+    float bedge[BU];
+    unsigned rowmask = 0, edgemask = 0;
+    // loads of my stage t: DMA pieces of A into `slot`, B units into registers (clamped to my last stage)
+    auto fetch = [&](int t, const int slot) {
+        t = t < nmine ? t : nmine - 1;
+        const unsigned q0 = (unsigned)(blockIdx.x + t * S) * KP;
+        const unsigned f = q0 / uHW, px = q0 - f * uHW;
+        const long offa = (long)f * p.a_ns + px;
+#pragma unroll
+        for (int j = 0; j < PPW; ++j)
+            __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(prow[j] + offa),
+                                             (__attribute__((address_space(3))) void*)(lds_raw + slot * ASLOT + (wave + j * NW) * 1024),
+                                             16, 0, 0);
+        const unsigned pix = px + 8u * kg;
+        const int y = (int)(pix / (unsigned)p.W), x0 = (int)(pix - (unsigned)y * (unsigned)p.W);
+        rowmask = 0;
+        edgemask = 0;
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            const int yy = y + udy[u];
+            const bool rok = yy >= 0 && yy < p.H;
+            const float* src = uplane[u] + (long)f * uns[u] + (rok ? yy : y) * p.W + x0;
+            bst[u][0] = *reinterpret_cast<const float4*>(src);
+            bst[u][1] = *reinterpret_cast<const float4*>(src + 4);
+            const bool eok = udx[u] < 0 ? x0 > 0 : x0 + 8 < p.W;
+            bedge[u] = src[eok ? (udx[u] < 0 ? -1 : 8) : 0];
+            rowmask |= (rok ? 1u : 0u) << u;
+            edgemask |= (eok ? 1u : 0u) << u;
+        }
+    };
+    auto commit = [&](const int buf) {
+        bf16x8* Bh = Bbase + buf * 2 * BPLANE;
+        bf16x8* Bl = Bh + BPLANE;
+#pragma unroll
+        for (int u = 0; u < BU; ++u) {
+            const int row = r0 + u * (NT / NU);
+            if (row < BN) {
+                const bool okr = n0 + row < p.N && ((rowmask >> u) & 1u);
+                const bool eok = (edgemask >> u) & 1u;
+                const float v[8] = {bst[u][0].x, bst[u][0].y, bst[u][0].z, bst[u][0].w,
+                                    bst[u][1].x, bst[u][1].y, bst[u][1].z, bst[u][1].w};
+                bf16x8 hi, lo;
+#pragma unroll
+                for (int c = 0; c < 8; ++c) {
+                    const float left = c == 0 ? (eok ? bedge[u] : 0.f) : v[c > 0 ? c - 1 : 0];
+                    const float right = c == 7 ? (eok ? bedge[u] : 0.f) : v[c < 7 ? c + 1 : 7];
+                    float x = udx[u] < 0 ? left : (udx[u] > 0 ? right : v[c]);
+                    x = okr ? x : 0.f;
+                    const __bf16 h = (__bf16)x;
+                    hi[c] = h;
+                    lo[c] = (__bf16)(x - (float)h);
+                }
+                Bh[row * RS + kg] = hi;
+                Bl[row * RS + kg] = lo;
+            }
+        }
+    };
+    auto rawA = [&](const unsigned char* sb, const int i, const int s_, f32x4 (&r)[2]) {
+        const int o = aoff[i] ^ (s_ << 6);
+        r[0] = *reinterpret_cast<const f32x4*>(sb + o);
+        r[1] = *reinterpret_cast<const f32x4*>(sb + (o ^ 16));
+    };
+    const int brow = (wn * TN * 32 + l31) * RS + kk;
+
+    // prologue: stage 0 loaded and committed
+    fetch(0, 0);
+    commit(0);
+    int slot = 0;
+    for (int it = 0; it < nmine; ++it) {
+        wg_wait_vm<0>();                    // (my pieces of this stage: older than the B loads just committed)
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_s_barrier();       // everybody's pieces and planes of stage `it`; the other slot / buffer is free
+        fetch(it + 1, slot ^ 1);
+        const unsigned char* sb = lds_raw + slot * ASLOT;
+        const bf16x8* Bh = Bbase + slot * 2 * BPLANE;
+        const bf16x8* Bl = Bh + BPLANE;
+        f32x4 ra[2][TM][2];
+        bf16x8 ah[2][TM], al[2][TM];
+#pragma unroll
+        for (int i = 0; i < TM; ++i) rawA(sb, i, 0, ra[0][i]);
+#pragma unroll
+        for (int i = 0; i < TM; ++i) wg_split8(ra[0][i][0], ra[0][i][1], ah[0][i], al[0][i]);
+#pragma unroll
+        for (int s_ = 0; s_ < NK; ++s_) {
+            const int cur = s_ & 1;
+            if (s_ + 1 < NK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) rawA(sb, i, s_ + 1, ra[cur ^ 1][i]);
+            }
+            bf16x8 bh[TN], bl[TN];
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                bh[j] = Bh[brow + j * 32 * RS + 2 * s_];
+                bl[j] = Bl[brow + j * 32 * RS + 2 * s_];
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(al[cur][i], bh[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][i], bl[j], acc[i][j], 0, 0, 0);
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah[cur][i], bh[j], acc[i][j], 0, 0, 0);
+                }
+            if (s_ + 1 < NK) {
+#pragma unroll
+                for (int i = 0; i < TM; ++i) wg_split8(ra[cur ^ 1][i][0], ra[cur ^ 1][i][1], ah[cur ^ 1][i], al[cur ^ 1][i]);
+            }
+        }
+        commit(slot ^ 1);   // B planes of stage it + 1 (nobody reads that buffer before the next barrier)
+        slot ^= 1;
+    }
+    wg_wait_vm<0>();
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int n = n0 + (wn * TN + j) * 32 + l31;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
+                if (m < p.M && n < p.N) atomicAdd(&p.gw[(long)m * p.N + n], acc[i][j][r]);
+            }
+        }
+}
+
+template <int WM, int WN, int TM, int TN>
+static void launch_gemm_wgrad_dma_impl(GemmWgradParams& p, hipStream_t s) {
+    constexpr int BM = 32 * TM * WM, BN = 32 * TN * WN;
+    p.n_stages = (int)(p.total / 32);
+    const size_t lds = (size_t)2 * BM * 128 + (size_t)2 * 2 * BN * 5 * 16;
+    const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
+    int S = 256 / tiles;
+    if (S > p.n_stages / 8) S = p.n_stages / 8;
+    if (S < 1) S = 1;
+    auto kern = gemm_wgrad_dma_impl_kernel<WM, WN, TM, TN>;
+    (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
+    hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
+}
+
 // shapes the LDS-DMA kernel takes: a plain (1x1-form, not grouped) gradient over whole 32-pixel stages
 static bool wgrad_dma_ok(const GemmWgradParams& p) {
     static const int off = getenv("RFN_WGRAD_DMA") ? atoi(getenv("RFN_WGRAD_DMA")) == 0 : 0;
@@ -587,7 +796,10 @@ extern "C" int rfn_gemm_wgrad_grouped_bf16x3(const float* const* a, long a_ns, i
 // (pad 1), the shifted planes built while staging (rows of one image row, W % 8 == 0).  The output is the torch weight
 // layout [Cout][Cin][3][3] (the GEMM on rfn_im2col3x3_f32's buffer gives [Cout][tap][Cin] instead).
 static void select_wgrad_implicit(GemmWgradParams& p, hipStream_t s) {
-    if (p.M > 128 && p.total >= 100000)
+    static const int dma_off = getenv("RFN_WGRAD_DMA") ? atoi(getenv("RFN_WGRAD_DMA")) == 0 : 0;
+    if (p.M > 128 && p.total >= 100000 && !dma_off && p.G == 0 && p.HW % 32 == 0 && p.a_ns % 4 == 0)
+        launch_gemm_wgrad_dma_impl<4, 2, 2, 3>(p, s);   // 256 x 192, 8 waves, A through the DMA ring
+    else if (p.M > 128 && p.total >= 100000)
         launch_gemm_wgrad<4, 2, 2, 3, 64, 1>(p, s);   // 256 x 192, 8 waves
     else if (p.M <= 32 && p.G == 0)
         // few output channels (the 16- / 32-channel blocks of the extractor / upscaler on 64x64 and 32x32 maps): one 32-row

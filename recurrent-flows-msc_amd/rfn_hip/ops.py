@@ -449,9 +449,11 @@ def conv2d_wgrad_b3(in1, in2, g, Cout, ks, arena=None):
         gp, gns = L.frames(g, "g")
         gw = _zeros(arena, Cout, 9 * Cin, device=in1.device)
         big = Cout > 128 and N * H * W >= 100000
+        dma = (big and (H * W) % 32 == 0 and gns % 4 == 0 and os.environ.get("RFN_WGRAD_DMA", "1") != "0")
         L.call("rfn_conv3x3_wgrad_implicit_bf16x3", gp, _l(gns), _i(Cout), i1p, _l(i1ns), _i(C1), i2p, _l(i2ns), _i(C2),
                L.dev(gw), _i(N), _i(H), _i(W),
-               meta=("wgrad", "gemm_wgrad_b3_kernel<%s,1>" % ("4,2,2,3,64" if big else ("1,4,1,2,32" if Cout <= 32 else "2,2,2,2,64")),
+               meta=("wgrad", "gemm_wgrad_dma_impl_kernel<4,2,2,3>" if dma else
+                     "gemm_wgrad_b3_kernel<%s,1>" % ("4,2,2,3,64" if big else ("1,4,1,2,32" if Cout <= 32 else "2,2,2,2,64")),
                      2.0 * N * H * W * Cout * 9 * Cin, "F%d %dx%d HW%d implicit3x3" % (N, Cout, 9 * Cin, H * W),
                      4.0 * (N * H * W * (Cout + Cin) + Cout * 9 * Cin)))
         return gw.view(Cout, Cin, 3, 3)  # rows of the implicit operand are (ci, tap): already the torch layout

@@ -420,6 +420,28 @@ def test_gemm_wgrad_tilings(K, M, Nc, F_, H, view):
     assert relerr(gw, ref.float()) < 2e-5
 
 
+@pytest.mark.parametrize("N,C1,C2,Cout,S", [(100, 2, 16, 256, 32), (401, 4, 32, 256, 16), (131, 6, 0, 200, 32)])
+def test_conv3x3_wgrad_implicit_big(K, N, C1, C2, Cout, S):
+    """rfn_conv3x3_wgrad_implicit_bf16x3 at >= 100000 pixels and more than 128 output channels -- conv1's weight gradient
+    at the two finest flow levels -- where the gradient image goes through the LDS-DMA ring and the shifted input planes
+    through the register-staged double buffer (gemm_wgrad_dma_impl_kernel): two-source input whose first source is a
+    channel slice of a wider tensor (z[:, :C/2]), 324 columns = two column tiles, uneven stage shares (401 frames of
+    16x16 = 3208 stages over 128 workgroups), Cout not a multiple of the tile; against F.conv2d's weight gradient (fp64)."""
+    if not K.bwd_b3():
+        pytest.skip("split-precision GEMM only")
+    g = torch.Generator().manual_seed(71)
+    z = torch.randn(N, 2 * C1, S, S, generator=g)
+    cond = torch.randn(N, C2, S, S, generator=g) if C2 else None
+    gy = torch.randn(N, Cout, S, S, generator=g)
+    xin = z[:, :C1] if cond is None else torch.cat((z[:, :C1], cond), 1)
+    w = torch.zeros(Cout, C1 + C2, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(xin.double(), w, padding=1).backward(gy.double())
+    zg = cu(z)
+    gw = K.conv2d_wgrad(zg[:, :C1], None if cond is None else cu(cond), cu(gy), Cout, 3)
+    torch.cuda.synchronize()
+    assert relerr(gw, w.grad.float()) < 2e-5
+
+
 @pytest.mark.parametrize("B,Cin,Cout,H,W", [(32, 768, 256, 2, 2), (4, 256, 112, 2, 2), (3, 10, 6, 4, 4), (40, 16, 8, 1, 2),
                                              (5, 6, 10, 2, 4)])
 @pytest.mark.parametrize("slope", [0.2, None])
