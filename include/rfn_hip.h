@@ -256,7 +256,7 @@ int rfn_conv3x3_smallcout_bf16x3(const float* in, long in_ns, int Cin, const flo
  * zeroes it).  1x1 weight gradients use it directly (a = output grad, b = conv input); 3x3 ones first expand the
  * smaller operand: b = rfn_im2col3x3_f32(input) [9*Cin rows, tap-major] or a = rfn_tap_scatter_f32(grad) [9*Cout rows].
  * Kernel choice (same arithmetic, same result up to summation order): F*HW >= 100000 pixels, HW % 32 == 0 and
- * Nc % 256 == 0 with M > 128 or M <= 64 -> the LDS-DMA ring kernel (raw fp32 rows HBM -> LDS by global_load_lds, split
+ * Nc % 256 == 0 with M >= 192 or M <= 64 (grouped form: G * F*HW >= 100000) -> the LDS-DMA ring kernel (raw fp32 rows HBM -> LDS by global_load_lds, split
  * at the fragment reads; RFN_WGRAD_DMA=0 disables it); otherwise the register-staged tilings (RFN_WGRAD_VARIANT,
  * RFN_WGRAD_SPLIT: tile / K-split experiments). */
 int rfn_gemm_wgrad_bf16x3(const float* a, long a_ns, int M, const float* b, long b_ns, int Nc, float* gw, int F, int HW,

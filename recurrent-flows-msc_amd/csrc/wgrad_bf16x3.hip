@@ -36,6 +36,25 @@ struct GemmWgradParams {
     float* ggw[16];
 };
 
+// operands of group `grp` of a grouped launch (or the single gradient's).  The group tables are read with
+// COMPILE-TIME indices: a run-time index into the by-value parameter struct keeps the whole struct in scratch memory
+// (632 bytes per lane, every field read through it -- what every kernel of this file did until round 3).
+struct WgOperands { const float* a; const float* b; const float* b2; float* gw; };
+__device__ __forceinline__ WgOperands wg_operands(const GemmWgradParams& p, const int grp) {
+    WgOperands o = {p.a, p.b, p.b2, p.gw};
+    if (p.G > 0) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i)
+            if (i == grp) {
+                o.a = p.ga[i];
+                o.b = p.gb[i];
+                o.b2 = p.gb2[i];
+                o.gw = p.ggw[i];
+            }
+    }
+    return o;
+}
+
 // WM x WN waves (4 or 8) of TM x TN 32x32 tiles each.  The 8-wave 256-row configurations read both operands of the
 // big level-0 / level-1 gradients exactly once (a 128 x 128 tiling of a 256 x 256 gradient reads each of them twice,
 // and those launches sit on the HBM roof).
@@ -59,10 +78,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_b3_kernel(const GemmW
     const int l31 = lane & 31, kk = lane >> 5;
     const int grp = p.G > 0 ? (int)blockIdx.z / p.mtiles : 0;
     const int m0 = (p.G > 0 ? (int)blockIdx.z - grp * p.mtiles : (int)blockIdx.z) * BM, n0 = blockIdx.y * BN;
-    const float* const pa_ = p.G > 0 ? p.ga[grp] : p.a;
-    const float* const pb_ = p.G > 0 ? p.gb[grp] : p.b;
-    const float* const pb2_ = p.G > 0 ? p.gb2[grp] : p.b2;
-    float* const pgw_ = p.G > 0 ? p.ggw[grp] : p.gw;
+    const WgOperands ops_ = wg_operands(p, grp);
+    const float* const pa_ = ops_.a;
+    const float* const pb_ = ops_.b;
+    const float* const pb2_ = ops_.b2;
+    float* const pgw_ = ops_.gw;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -305,7 +325,13 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_kernel(const Gemm
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, kk = lane >> 5;
-    const int m0 = blockIdx.z * BM, n0 = blockIdx.y * BN;
+    // grouped launch (G > 0): blockIdx.z = group * mtiles + row tile; the groups share shapes and strides
+    const int grp = p.G > 0 ? (int)blockIdx.z / p.mtiles : 0;
+    const int m0 = (p.G > 0 ? (int)blockIdx.z - grp * p.mtiles : (int)blockIdx.z) * BM, n0 = blockIdx.y * BN;
+    const WgOperands ops_ = wg_operands(p, grp);
+    const float* const pa_ = ops_.a;
+    const float* const pb_ = ops_.b;
+    float* const pgw_ = ops_.gw;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -326,11 +352,11 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_kernel(const Gemm
         if (pisa[j]) {
             int row = m0 + r;
             row = row < p.M ? row : p.M - 1;
-            prow[j] = p.a + (long)row * p.HW + 4 * u;
+            prow[j] = pa_ + (long)row * p.HW + 4 * u;
         } else {
             int row = n0 + r - BM;
             row = row < p.N ? row : p.N - 1;
-            prow[j] = p.b + (long)row * p.HW + 4 * u;
+            prow[j] = pb_ + (long)row * p.HW + 4 * u;
         }
     }
     const unsigned uHW = (unsigned)p.HW;
@@ -474,7 +500,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_kernel(const Gemm
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (m < p.M && n < p.N) atomicAdd(&p.gw[(long)m * p.N + n], acc[i][j][r]);
+                if (m < p.M && n < p.N) atomicAdd(&pgw_[(long)m * p.N + n], acc[i][j][r]);
             }
         }
 }
@@ -485,12 +511,14 @@ static void launch_gemm_wgrad_dma(GemmWgradParams& p, hipStream_t s) {
     p.n_stages = (int)(p.total / KP);
     const size_t lds = (size_t)NST * (BM + BN) * KP * 4;
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    int S = 256 / tiles;   // one 8-wave workgroup per CU (see launch_gemm_wgrad)
+    const int G = p.G > 0 ? p.G : 1;
+    int S = 256 / (tiles * G);   // one 8-wave workgroup per CU (see launch_gemm_wgrad)
     if (S > p.n_stages / 8) S = p.n_stages / 8;
     if (S < 1) S = 1;
     auto kern = gemm_wgrad_dma_kernel<WM, WN, TM, TN, KP, NST>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
+    p.mtiles = ceil_div(p.M, BM);
+    dim3 grid(S, ceil_div(p.N, BN), p.mtiles * G);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
 }
 
@@ -517,7 +545,14 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_impl_kernel(const
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wm = wave / WN, wn = wave % WN;
     const int l31 = lane & 31, kk = lane >> 5;
-    const int m0 = blockIdx.z * BM, n0 = blockIdx.y * BN;
+    // grouped launch (G > 0): blockIdx.z = group * mtiles + row tile; the groups share shapes and strides
+    const int grp = p.G > 0 ? (int)blockIdx.z / p.mtiles : 0;
+    const int m0 = (p.G > 0 ? (int)blockIdx.z - grp * p.mtiles : (int)blockIdx.z) * BM, n0 = blockIdx.y * BN;
+    const WgOperands ops_ = wg_operands(p, grp);
+    const float* const pa_ = ops_.a;
+    const float* const pb_ = ops_.b;
+    const float* const pb2_ = ops_.b2;
+    float* const pgw_ = ops_.gw;
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -535,7 +570,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_impl_kernel(const
         const int u = (lane & 7) ^ ((r >> 1) & 7);
         int row = m0 + r;
         row = row < p.M ? row : p.M - 1;
-        prow[j] = p.a + (long)row * p.HW + 4 * u;
+        prow[j] = pa_ + (long)row * p.HW + 4 * u;
     }
     int aoff[TM];
 #pragma unroll
@@ -556,7 +591,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_impl_kernel(const
         udy[u] = tap / 3 - 1;
         udx[u] = tap % 3 - 1;
         const bool first = ci < p.C1;
-        uplane[u] = first ? p.b + (long)ci * p.HW : p.b2 + (long)(ci - p.C1) * p.HW;
+        uplane[u] = first ? pb_ + (long)ci * p.HW : pb2_ + (long)(ci - p.C1) * p.HW;
         uns[u] = first ? p.b_ns : p.b2_ns;
     }
     const unsigned uHW = (unsigned)p.HW;
@@ -683,7 +718,7 @@ __global__ __launch_bounds__(64 * WM * WN) void gemm_wgrad_dma_impl_kernel(const
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int m = m0 + (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * kk;
-                if (m < p.M && n < p.N) atomicAdd(&p.gw[(long)m * p.N + n], acc[i][j][r]);
+                if (m < p.M && n < p.N) atomicAdd(&pgw_[(long)m * p.N + n], acc[i][j][r]);
             }
         }
 }
@@ -694,19 +729,23 @@ static void launch_gemm_wgrad_dma_impl(GemmWgradParams& p, hipStream_t s) {
     p.n_stages = (int)(p.total / 32);
     const size_t lds = (size_t)2 * BM * 128 + (size_t)2 * 2 * BN * 5 * 16;
     const int tiles = ceil_div(p.M, BM) * ceil_div(p.N, BN);
-    int S = 256 / tiles;
+    const int G = p.G > 0 ? p.G : 1;
+    int S = 256 / (tiles * G);
     if (S > p.n_stages / 8) S = p.n_stages / 8;
     if (S < 1) S = 1;
     auto kern = gemm_wgrad_dma_impl_kernel<WM, WN, TM, TN>;
     (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    dim3 grid(S, ceil_div(p.N, BN), ceil_div(p.M, BM));
+    p.mtiles = ceil_div(p.M, BM);
+    dim3 grid(S, ceil_div(p.N, BN), p.mtiles * G);
     hipLaunchKernelGGL(kern, grid, dim3(64 * WM * WN), lds, s, p);
 }
 
-// shapes the LDS-DMA kernel takes: a plain (1x1-form, not grouped) gradient over whole 32-pixel stages
+// shapes the LDS-DMA kernel takes: a plain (1x1-form) gradient -- or a group of them -- over whole 32-pixel stages
 static bool wgrad_dma_ok(const GemmWgradParams& p) {
     static const int off = getenv("RFN_WGRAD_DMA") ? atoi(getenv("RFN_WGRAD_DMA")) == 0 : 0;
-    return !off && p.G == 0 && p.HW % 32 == 0 && p.total >= 100000 && p.a_ns % 4 == 0 && p.b_ns % 4 == 0 && p.N > 128;
+    // (grouped: the K gradients of a level together are the problem size)
+    return !off && p.HW % 32 == 0 && p.total * (p.G > 0 ? p.G : 1) >= 100000 && p.total >= 2048 && p.a_ns % 4 == 0 &&
+           p.b_ns % 4 == 0 && p.N > 128;
 }
 
 template <int WM, int WN, int TM, int TN, int KP, int IMPL = 0>
@@ -734,7 +773,7 @@ static void select_gemm_wgrad(GemmWgradParams& p, hipStream_t s) {
     const int M = p.M, Nc = p.N;
     static const int variant = getenv("RFN_WGRAD_VARIANT") ? atoi(getenv("RFN_WGRAD_VARIANT")) : 0;
     if (variant == 0 && wgrad_dma_ok(p)) {
-        if (M > 128 && Nc % 256 == 0) return launch_gemm_wgrad_dma<2, 4, 4, 2, 32, 2>(p, s);   // 256 x 256, two slots of 64 KB
+        if (M >= 192 && Nc % 256 == 0) return launch_gemm_wgrad_dma<2, 4, 4, 2, 32, 2>(p, s);   // 256 x 256, two slots of 64 KB
         if (M <= 64 && Nc % 256 == 0) return launch_gemm_wgrad_dma<1, 8, 2, 1, 32, 3>(p, s);   // 64 x 256, ring of 3 x 40 KB
     }
     const bool big = variant != 1 && M > 128 && Nc > 128 && p.total >= 100000;
@@ -797,7 +836,8 @@ extern "C" int rfn_gemm_wgrad_grouped_bf16x3(const float* const* a, long a_ns, i
 // layout [Cout][Cin][3][3] (the GEMM on rfn_im2col3x3_f32's buffer gives [Cout][tap][Cin] instead).
 static void select_wgrad_implicit(GemmWgradParams& p, hipStream_t s) {
     static const int dma_off = getenv("RFN_WGRAD_DMA") ? atoi(getenv("RFN_WGRAD_DMA")) == 0 : 0;
-    if (p.M > 128 && p.total >= 100000 && !dma_off && p.G == 0 && p.HW % 32 == 0 && p.a_ns % 4 == 0)
+    // (grouped: the K gradients of a level together are the problem size)
+    if (p.M > 128 && p.total * (p.G > 0 ? p.G : 1) >= 100000 && p.total >= 2048 && !dma_off && p.HW % 32 == 0 && p.a_ns % 4 == 0)
         launch_gemm_wgrad_dma_impl<4, 2, 2, 3>(p, s);   // 256 x 192, 8 waves, A through the DMA ring
     else if (p.M > 128 && p.total >= 100000)
         launch_gemm_wgrad<4, 2, 2, 3, 64, 1>(p, s);   // 256 x 192, 8 waves

@@ -205,11 +205,16 @@ class PackPlan:
 
 
 # ------------------------------------------------------------------------------------------------ fused coupling net
-def coupling_po_ok(N, C, Cc, Hd, H, W, w1, w3):
-    """shapes the fused forward kernel (csrc/coupling_po.hip) takes; both 3x3 convs must really be 3x3"""
+def coupling_po_ok(N, C, Cc, Hd, H, W, w1, w3, any_size=False):
+    """shapes the fused forward kernel (csrc/coupling_po.hip) takes; both 3x3 convs must really be 3x3.
+    Policy on top of the capability (skipped with any_size): the wide instantiations (more than 40 input channels: level
+    2 of the canonical flow) take ~65 us per 128-pixel round -- with fewer rounds than half the CUs (a local batch of 4
+    or 8) the three unfused launches, which spread the same work over the whole chip, are faster."""
     if os.environ.get("RFN_COUPLING_PO") == "0" or CONV_PRECISION != "mixed":
         return False
     if tuple(w1.shape[2:]) != (3, 3) or tuple(w3.shape[2:]) != (3, 3):
+        return False
+    if not any_size and C // 2 + Cc > 40 and N * H * W < 128 * 128:
         return False
     return bool(L.load().rfn_coupling_po_supported(int(N), int(C), int(Cc), int(Hd), int(H), int(W)))
 
@@ -409,11 +414,12 @@ def wgrad_kernel_name(Cout, Cin, ks, HW):
     return "wgrad_mfma_kernel<%d,%s,64>" % (ks, cfg)
 
 
-def _gemm_wgrad_name(M, Nc, total, HW=0, ans=0, bns=0):
+def _gemm_wgrad_name(M, Nc, total, HW=0, ans=0, bns=0, G=1):
     """mirror of the kernel / tile choice in rfn_gemm_wgrad_bf16x3 (csrc/wgrad_bf16x3.hip), for profiling labels only"""
-    if (os.environ.get("RFN_WGRAD_DMA", "1") != "0" and not os.environ.get("RFN_WGRAD_VARIANT") and total >= 100000
-            and HW % 32 == 0 and ans % 4 == 0 and bns % 4 == 0 and Nc > 128 and Nc % 256 == 0 and (M > 128 or M <= 64)):
-        return "gemm_wgrad_dma_kernel<%s>" % ("2,4,4,2,2" if M > 128 else "1,8,2,1,3")
+    if (os.environ.get("RFN_WGRAD_DMA", "1") != "0" and not os.environ.get("RFN_WGRAD_VARIANT") and total * G >= 100000
+            and total >= 2048 and HW % 32 == 0 and ans % 4 == 0 and bns % 4 == 0 and Nc > 128 and Nc % 256 == 0
+            and (M >= 192 or M <= 64)):
+        return "gemm_wgrad_dma_kernel<%s>" % ("2,4,4,2,32,2" if M > 128 else "1,8,2,1,32,3")
     if M > 128 and Nc > 128 and total >= 100000:
         cfg = "4,2,2,3,64" if -(-Nc // 192) * 192 < -(-Nc // 256) * 256 else "2,4,4,2,64"
     else:
@@ -482,7 +488,7 @@ def gemm_wgrad_grouped(a_list, b_list, M, Nc, arena=None):
     pa, pb = L.ptr_array(a_list, "a"), L.ptr_array(b_list, "b")
     pg = L.ptr_array([gw[g] for g in range(G)], "gw")
     L.call("rfn_gemm_wgrad_grouped_bf16x3", pa, _l(ans), _i(M), pb, _l(bns), _i(Nc), pg, _i(G), _i(F_), _i(HW),
-           meta=("wgrad", _gemm_wgrad_name(M, Nc, F_ * HW, 1).replace("<", "<grouped "),
+           meta=("wgrad", _gemm_wgrad_name(M, Nc, F_ * HW, HW, ans, bns, G).replace("<", "<grouped "),
                  2.0 * G * F_ * HW * M * Nc, "G%d F%d %dx%d HW%d" % (G, F_, M, Nc, HW),
                  4.0 * G * (F_ * HW * (M + Nc) + M * Nc)))
     return gw
@@ -515,7 +521,10 @@ def conv2d_wgrad_grouped(in1_list, in2_list, g_list, Cout, ks, arena=None, g_sta
         pw = L.ptr_array([gw[i] for i in range(G)], "gw")
         L.call("rfn_conv3x3_wgrad_implicit_grouped_bf16x3", pg, _l(gns), _i(Cout), p1, _l(i1ns), _i(C1), p2, _l(i2ns),
                _i(C2), pw, _i(G), _i(N), _i(H), _i(W),
-               meta=("wgrad", "gemm_wgrad_b3_kernel<grouped implicit>", 2.0 * G * N * H * W * Cout * 9 * Cin,
+               meta=("wgrad", "gemm_wgrad_dma_impl_kernel<grouped 4,2,2,3>" if (
+                         Cout > 128 and G * N * H * W >= 100000 and N * H * W >= 2048 and (H * W) % 32 == 0 and gns % 4 == 0
+                         and os.environ.get("RFN_WGRAD_DMA", "1") != "0") else "gemm_wgrad_b3_kernel<grouped implicit>",
+                     2.0 * G * N * H * W * Cout * 9 * Cin,
                      "G%d F%d %dx%d HW%d implicit3x3" % (G, N, Cout, 9 * Cin, H * W),
                      4.0 * G * (N * H * W * (Cout + Cin) + Cout * 9 * Cin)))
         return [gw[i].view(Cout, Cin, 3, 3) for i in range(G)]

@@ -400,7 +400,7 @@ def test_gauss_logp_fwd_bwd_sample(K, layout, std_mode):
 
 @pytest.mark.parametrize("M,Nc,F_,H,view", [(256, 256, 100, 32, False), (256, 162, 100, 32, False), (200, 324, 400, 16, False),
                                             (256, 256, 3, 8, False), (256, 256, 131, 32, True), (36, 256, 100, 32, False),
-                                            (72, 256, 401, 16, True), (144, 256, 1700, 8, False)])
+                                            (72, 256, 401, 16, True), (144, 256, 1700, 8, False), (200, 256, 1700, 8, False)])
 def test_gemm_wgrad_tilings(K, M, Nc, F_, H, view):
     """rfn_gemm_wgrad_bf16x3: gw[m][n] = sum over frames and pixels of a*b, against an fp64 einsum, on every kernel it
     selects: the LDS-DMA ring kernel (>= 100000 pixels, HW % 32 == 0, 256-column gradients: 256 x 256 and <= 64 x 256
@@ -418,6 +418,34 @@ def test_gemm_wgrad_tilings(K, M, Nc, F_, H, view):
     gw = K.gemm_wgrad(ag[:, :M], bg[:, 4:] if view else bg, M, Nc)
     torch.cuda.synchronize()
     assert relerr(gw, ref.float()) < 2e-5
+
+
+@pytest.mark.parametrize("G,N,C1,C2,Cout,S,ks", [(3, 600, 8, 64, 256, 8, 3), (4, 40, 2, 16, 256, 32, 3), (3, 50, 4, 0, 64, 8, 3),
+                                                 (3, 70, 256, 0, 256, 8, 1), (2, 60, 256, 0, 16, 8, 3), (3, 33, 16, 128, 256, 4, 3)])
+def test_conv2d_wgrad_grouped(K, G, N, C1, C2, Cout, S, ks):
+    """conv2d_wgrad_grouped: the weight gradients of G convolutions of one shape in one launch (the K steps of a flow
+    level) against one fp64 F.conv2d weight gradient per group.  256 output channels on 8x8 / 32x32 maps with
+    G * pixels >= 100000 take the grouped form of the LDS-DMA ring kernel (level 2 of the canonical flow at the bench's
+    size; level 0 at a local batch of 2), the others the 128 x 128 tiles: implicit 3x3, plain 1x1, tap-scattered 3x3
+    (few output channels), im2col 3x3 (4x4 maps)."""
+    if not K.bwd_b3():
+        pytest.skip("split-precision GEMM only")
+    g = torch.Generator().manual_seed(72)
+    in1 = [torch.randn(N, C1, S, S, generator=g) for _ in range(G)]
+    in2 = [torch.randn(N, C2, S, S, generator=g) for _ in range(G)] if C2 else None
+    gy = torch.randn(G, N, Cout, S, S, generator=g)
+    refs = []
+    for i in range(G):
+        xin = in1[i] if in2 is None else torch.cat((in1[i], in2[i]), 1)
+        w = torch.zeros(Cout, C1 + C2, ks, ks, dtype=torch.float64, requires_grad=True)
+        F.conv2d(xin.double(), w, padding=ks // 2).backward(gy[i].double())
+        refs.append(w.grad.float())
+    gyc = cu(gy)
+    gws = K.conv2d_wgrad_grouped([cu(t) for t in in1], None if in2 is None else [cu(t) for t in in2],
+                                 [gyc[i] for i in range(G)], Cout, ks, g_stacked=gyc)
+    torch.cuda.synchronize()
+    for i in range(G):
+        assert relerr(gws[i], refs[i]) < 2e-5, i
 
 
 @pytest.mark.parametrize("N,C1,C2,Cout,S", [(100, 2, 16, 256, 32), (401, 4, 32, 256, 16), (131, 6, 0, 200, 32)])
@@ -619,7 +647,7 @@ def test_coupling_po_fused_forward(K, N, C, Cc, S, act, conv_precision):
     h1r = actf((F.conv2d(xin.double(), w1.double(), padding=1) + n1b.double().view(1, -1, 1, 1)) * n1l.double().exp().view(1, -1, 1, 1))
     h2r = actf((F.conv2d(h1r, w2.double()) + n2b.double().view(1, -1, 1, 1)) * n2l.double().exp().view(1, -1, 1, 1))
     orf = (F.conv2d(h2r, w3.double(), b3.double(), padding=1)) * torch.exp(3 * l3.double()).view(1, -1, 1, 1)
-    assert K.coupling_po_ok(N, C, Cc, 256, S, S, w1, w3)
+    assert K.coupling_po_ok(N, C, Cc, 256, S, S, w1, w3, any_size=True)
     w1c, w2c, w3c = cu(w1), cu(w2), cu(w3)
     plan = K.POPackPlan([(w1c, w2c, w3c)])
     plan.run()
@@ -660,7 +688,7 @@ def test_coupling_po_fused_backward(K, N, C, Cc, S, act, conv_precision):
     n1b, n1l = torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
     n2b, n2l = torch.randn(256, generator=g) * 0.1, torch.randn(256, generator=g) * 0.1
     go = torch.randn(N, C, S, S, generator=g)
-    assert K.coupling_po_ok(N, C, Cc, 256, S, S, w1, w3) and K.coupling_po_bwd_ok(N, C, S, S)
+    assert K.coupling_po_ok(N, C, Cc, 256, S, S, w1, w3, any_size=True) and K.coupling_po_bwd_ok(N, C, S, S)
     w1c, w2c, w3c = cu(w1), cu(w2), cu(w3)
     plan = K.POPackPlan([(w1c, w2c, w3c)])
     plan.run()
