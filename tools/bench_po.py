@@ -6,6 +6,9 @@ for p in (ROOT, os.path.join(ROOT, "recurrent-flows-msc_amd")):
     sys.path.insert(0, p)
 import torch
 from rfn_hip import ops as K
+from rfn_hip import lib as _L
+if os.environ.get("RFN_LIB"):   # A/B of two builds of the library on one box
+    _L.LIB_PATH = os.path.join(ROOT, os.environ["RFN_LIB"])
 
 def run(N, C, Cc, S, reps=10):
     g = torch.Generator().manual_seed(0)
