@@ -366,6 +366,14 @@ int rfn_latent_step_bwd_f32(const float* enc, const float* pri, const float* eps
 long rfn_smallmap_packed_size(int Cout, int Cin, int H, int W, int transpose);
 int rfn_smallmap_pack_bf16x3(const float* w, int Cout, int Cin, int H, int W, int transpose, float* packed,
                              rfn_stream_t stream);
+/* The same for n matrices in ceil(n / 64) launches: host array of descriptors (the packs of one training step -- latent
+ * nets, ConvLSTM, the 2x2 flow level -- are queued by the host and flushed before their first consumer). */
+typedef struct {
+    const float* w;   /* [Cout][Cin][3][3] */
+    float* packed;    /* rfn_smallmap_packed_size(Cout, Cin, H, W, transpose) bytes, 16-byte aligned */
+    int Cout, Cin, H, W, transpose, pad_;
+} rfn_smallmap_pack_desc;
+int rfn_smallmap_pack_batched_bf16x3(const void* descs_host, int n, rfn_stream_t stream);
 int rfn_smallmap_dense_bf16x3(const float* a, const float* y, float slope_in, const float* packed, const float* bias,
                               const float* add, int act_out, float slope_out, float* out, float* a_out, int B, int K, int N,
                               int HW, rfn_stream_t stream);

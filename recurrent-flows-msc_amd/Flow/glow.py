@@ -218,6 +218,34 @@ class ListGlow(nn.Module):
                 slots[s] = slot
             if split is not None:
                 C = C // 2
+        # the dense packs of the small-map levels (H*W <= 16: level 4 of the canonical flow), forward and -- when a
+        # gradient will be asked for -- data-gradient orientation: queued here, all of them leave in ONE launch before the
+        # first kernel that reads one (rfn_hip.ops.smallmap_pack).  Re-packed on every call like the plans below: a
+        # captured training step must contain the launch (a version-keyed cache would be hit during capture and the
+        # replays would run on stale packs).
+        dense = {}
+        Cd, Hd_, Wd_ = (int(v) for v in x_shape[1:])
+
+        def dense_pack(s_, slot, w, transpose):
+            return K.smallmap_pack(w, Hd_, Wd_, transpose)
+
+        for l, (_, steps, split) in enumerate(levels):
+            Cd, Hd_, Wd_ = Cd * 4, Hd_ // 2, Wd_ // 2
+            Ccd = int(condition[l].shape[1])
+            for s in steps:
+                w1, w3 = s.affine.net[0].conv.weight, s.affine.net[4].conv.weight
+                k33 = int(w1.shape[2]) == 3 and int(w3.shape[2]) == 3
+                d8 = d9 = d10 = None
+                if k33 and K.smallmap_conv_ok(Hd_, Wd_, Cd // 2, Ccd, int(w1.shape[0]), N):
+                    d8 = dense_pack(s, 8, w1, False)
+                if k33 and K.smallmap_conv_ok(Hd_, Wd_, int(w1.shape[0]), 0, Cd, N) and not K.zeros_conv_uses_taps(w3):
+                    d9 = dense_pack(s, 9, w3, False)
+                if (torch.is_grad_enabled() and k33
+                        and K.smallmap_conv_ok(Hd_, Wd_, int(w1.shape[0]), 0, Cd // 2 + Ccd, N, bwd=True)):
+                    d10 = dense_pack(s, 10, w1, True)
+                dense[s] = (d8, d9, d10)
+            if split is not None:
+                Cd = Cd // 2
         plan = getattr(self, "_pack_plan", None)
         if plan is None or not plan.valid_for(items):
             plan = self._pack_plan = K.PackPlan(items)
@@ -230,6 +258,7 @@ class ListGlow(nn.Module):
             po.run(bwd=torch.is_grad_enabled())
         return {s: tuple((None if i is None else plan.bufs[i]) for i in sl[:6])
                 + ((None if sl[6] is None else po.bufs[sl[6]]), (None if sl[6] is None else po.bwd_bufs[sl[6]]))
+                + dense[s]
                 for s, sl in slots.items()}
 
     def f(self, x, condition, logdet):

@@ -12,6 +12,7 @@ from torch.utils.data import DataLoader
 
 from data_generators import SyntheticMovingMNIST
 from rfn_hip import dist as rdist
+from rfn_hip import ops as K
 from Utils import set_gpu
 from .RFN_new import RFN
 
@@ -195,6 +196,7 @@ class Solver(object):
                     self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.current_stream().wait_stream(side)
             self.optimizer.zero_grad(set_to_none=True)
+            K.smallmap_pack_flush()   # (nothing queued outside may be launched -- and replayed -- inside the capture)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._graph_body()

@@ -17,34 +17,62 @@ typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 // ------------------------------------------------------------------------------------------------ packing
 // packed[((tile*KS + ks)*2 + plane)*64 + lane] (16-byte units): lane -> n = tile*32 + lane%32, k = ks*16 + (lane/32)*8 + j
 // transpose = 0: k = (ci,pi), n = (co,po)   (forward)        transpose = 1: k = (co,po), n = (ci,pi)   (data gradient)
+__device__ __forceinline__ void smallmap_pack_item(const float* __restrict__ w, const int Cout, const int Cin, const int H,
+                                                   const int W, const int transpose, bf16x8* __restrict__ packed,
+                                                   const int KS, const long idx);
 __global__ void smallmap_pack_kernel(const float* __restrict__ w, int Cout, int Cin, int H, int W, int transpose,
                                      bf16x8* __restrict__ packed, int KS, int NTILES) {
-    const int HW = H * W;
     const long total = (long)NTILES * KS * 64;
-    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-        const int lane = (int)(idx & 63);
-        const long r = idx >> 6;
-        const int ks = (int)(r % KS), tile = (int)(r / KS);
-        const int n = tile * 32 + (lane & 31);
-        const int kbase = ks * 16 + (lane >> 5) * 8;
-        bf16x8 hi, lo;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x)
+        smallmap_pack_item(w, Cout, Cin, H, W, transpose, packed, KS, idx);
+}
+
+// one fragment pair (hi, lo) of a packed matrix: the body of both pack kernels
+__device__ __forceinline__ void smallmap_pack_item(const float* __restrict__ w, const int Cout, const int Cin, const int H,
+                                                   const int W, const int transpose, bf16x8* __restrict__ packed,
+                                                   const int KS, const long idx) {
+    const int HW = H * W;
+    const int lane = (int)(idx & 63);
+    const long r = idx >> 6;
+    const int ks = (int)(r % KS), tile = (int)(r / KS);
+    const int n = tile * 32 + (lane & 31);
+    const int kbase = ks * 16 + (lane >> 5) * 8;
+    bf16x8 hi, lo;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
-            const int k = kbase + j;
-            const int cn = n / HW, pn = n - cn * HW, ck = k / HW, pk = k - ck * HW;
-            const int co = transpose ? ck : cn, po = transpose ? pk : pn;
-            const int ci = transpose ? cn : ck, pi = transpose ? pn : pk;
-            const int dy = pi / W - po / W + 1, dx = pi % W - po % W + 1;
-            float v = 0.f;
-            if (co < Cout && ci < Cin && dy >= 0 && dy < 3 && dx >= 0 && dx < 3)
-                v = w[((long)co * Cin + ci) * 9 + dy * 3 + dx];
-            const __bf16 h = (__bf16)v;
-            hi[j] = h;
-            lo[j] = (__bf16)(v - (float)h);
-        }
-        packed[(r * 2 + 0) * 64 + lane] = hi;
-        packed[(r * 2 + 1) * 64 + lane] = lo;
+    for (int j = 0; j < 8; ++j) {
+        const int k = kbase + j;
+        const int cn = n / HW, pn = n - cn * HW, ck = k / HW, pk = k - ck * HW;
+        const int co = transpose ? ck : cn, po = transpose ? pk : pn;
+        const int ci = transpose ? cn : ck, pi = transpose ? pn : pk;
+        const int dy = pi / W - po / W + 1, dx = pi % W - po % W + 1;
+        float v = 0.f;
+        if (co < Cout && ci < Cin && dy >= 0 && dy < 3 && dx >= 0 && dx < 3)
+            v = w[((long)co * Cin + ci) * 9 + dy * 3 + dx];
+        const __bf16 h = (__bf16)v;
+        hi[j] = h;
+        lo[j] = (__bf16)(v - (float)h);
     }
+    packed[(r * 2 + 0) * 64 + lane] = hi;
+    packed[(r * 2 + 1) * 64 + lane] = lo;
+}
+
+// Up to SM_PACK_MAX matrices in ONE launch (the weights change every optimizer step: the latent nets, the ConvLSTM and the
+// 2x2 flow level re-pack ~60 matrices per step, each a ~10 us launch of its own until round 3).  The descriptors travel
+// by value in the kernel arguments; block (x, y) works on matrix y.
+#define SM_PACK_MAX 64
+struct SmallmapPackDesc {   // mirrors rfn_smallmap_pack_desc in include/rfn_hip.h
+    const float* w;
+    float* packed;
+    int Cout, Cin, H, W, transpose, pad_;
+};
+struct SmallmapPackTable { SmallmapPackDesc d[SM_PACK_MAX]; };
+__global__ __launch_bounds__(256) void smallmap_pack_batched_kernel(const SmallmapPackTable t) {
+    const SmallmapPackDesc d = t.d[blockIdx.y];
+    const int HW = d.H * d.W;
+    const int KS = ((d.transpose ? d.Cout : d.Cin) * HW + 15) / 16, NT = ((d.transpose ? d.Cin : d.Cout) * HW + 31) / 32;
+    const long total = (long)NT * KS * 64;
+    for (long idx = (long)blockIdx.x * 256 + threadIdx.x; idx < total; idx += (long)gridDim.x * 256)
+        smallmap_pack_item(d.w, d.Cout, d.Cin, d.H, d.W, d.transpose, reinterpret_cast<bf16x8*>(d.packed), KS, idx);
 }
 
 static void smallmap_dims(int Cout, int Cin, int HW, int transpose, int* K, int* N, int* KS, int* NTILES) {
@@ -70,6 +98,33 @@ extern "C" int rfn_smallmap_pack_bf16x3(const float* w, int Cout, int Cin, int H
     const int grid = (int)((total + 255) / 256 < 4096 ? (total + 255) / 256 : 4096);
     hipLaunchKernelGGL(smallmap_pack_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, w, Cout, Cin, H, W, transpose,
                        reinterpret_cast<bf16x8*>(packed), KS, NT);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+/* n matrices (host array of descriptors) in ceil(n / 64) launches */
+extern "C" int rfn_smallmap_pack_batched_bf16x3(const void* descs_host, int n, rfn_stream_t stream) {
+    RFN_CHECK_ARG(descs_host && n >= 0, -1);
+    const SmallmapPackDesc* d = reinterpret_cast<const SmallmapPackDesc*>(descs_host);
+    for (int i = 0; i < n; ++i) {
+        RFN_CHECK_ARG(d[i].w && d[i].packed && d[i].Cout > 0 && d[i].Cin > 0 && d[i].H > 0 && d[i].W > 0 &&
+                      d[i].H * d[i].W <= 16 && ((uintptr_t)d[i].packed & 15) == 0, -2);
+    }
+    for (int i0 = 0; i0 < n; i0 += SM_PACK_MAX) {
+        const int m = n - i0 < SM_PACK_MAX ? n - i0 : SM_PACK_MAX;
+        SmallmapPackTable t;
+        memset(&t, 0, sizeof(t));
+        long most = 0;
+        for (int i = 0; i < m; ++i) {
+            t.d[i] = d[i0 + i];
+            int K, N, KS, NT;
+            smallmap_dims(t.d[i].Cout, t.d[i].Cin, t.d[i].H * t.d[i].W, t.d[i].transpose, &K, &N, &KS, &NT);
+            const long total = (long)NT * KS * 64;
+            most = total > most ? total : most;
+        }
+        const int gx = (int)((most + 255) / 256 < 512 ? (most + 255) / 256 : 512);
+        hipLaunchKernelGGL(smallmap_pack_batched_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)stream, t);
+    }
     RFN_LAUNCH_CHECK();
     return 0;
 }

@@ -98,6 +98,7 @@ SIGNATURES = {
                                 _c_s],
     "rfn_smallmap_packed_size": [_c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_smallmap_pack_bf16x3": [_c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_s],
+    "rfn_smallmap_pack_batched_bf16x3": [ctypes.c_void_p, _c_i, _c_s],
     "rfn_smallmap_dense_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i,
                                   _c_i, _c_i, _c_i, _c_s],
     "rfn_smallmap_dense_pair_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i,

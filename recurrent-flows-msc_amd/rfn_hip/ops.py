@@ -746,6 +746,11 @@ def _f(t):
     return None if t is None else t.detach().reshape(-1).contiguous()
 
 
+# per-step pack tuple handed to the coupling nets: [0..5] split-precision conv packs (w1 f, w1 d, w2 f, w2 d, w3 f, w3 d),
+# [6] / [7] fused forward / backward streams, [8] / [9] / [10] dense small-map packs (w1 forward, w3 forward, w1 data gradient)
+PACK_SLOTS = 11
+
+
 def dgrad_small_ok(N, Cin, Cout, H, W, ks):
     """the dedicated few-output-channel 3x3 kernel (csrc/dgrad_small.hip) serves this data-gradient convolution"""
     return (ks == 3 and bwd_b3() and os.environ.get("RFN_DGRAD_SMALL") != "0"
@@ -797,14 +802,15 @@ def _net_fwd(z, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk, want_mask
     dense3 = k33 and smallmap_conv_ok(H, W, Hd, 0, C, N) and not zeros_conv_uses_taps(w3)
     b3fwd = fp in ("bf16x3", "bf16x6")  # the caller's pack plan holds forward packs in this map's split arithmetic
     if dense:
-        h1 = smallmap_conv(z1, cin2, smallmap_pack(w1, H, W, False), Hd, 1, _f(n1b), _f(n1l), act)
+        h1 = smallmap_conv(z1, cin2, pk[8] if pk[8] is not None else smallmap_pack(w1, H, W, False), Hd, 1, _f(n1b),
+                           _f(n1l), act)
     else:
         h1 = conv2d_raw(z1, cin2, pk[0] if (pk[0] is not None and b3fwd) else pack_weight(w1, prec=fp), Hd,
                         int(w1.shape[2]), 1, _f(n1b), _f(n1l), act, prec=fp)
     h2 = conv2d_raw(h1, None, pk[2] if (pk[2] is not None and b3fwd) else pack_weight(w2, prec=fp), Hd,
                     int(w2.shape[2]), 1, _f(n2b), _f(n2l), act, prec=fp)
     if dense3:
-        o = smallmap_conv(h2, None, smallmap_pack(w3, H, W, False), C, 2, _f(b3), _f(l3), 0)
+        o = smallmap_conv(h2, None, pk[9] if pk[9] is not None else smallmap_pack(w3, H, W, False), C, 2, _f(b3), _f(l3), 0)
     else:
         o = zeros_conv_fwd(h2, w3, _f(b3), _f(l3), pk[4] if b3fwd else None, prec=fp)
     return h1, h2, o, None, None
@@ -867,7 +873,7 @@ def _net_bwd(go, out, cond, h1, h2, w1, n1l, w2, n2l, w3, act, pk, arena, gz, gc
         defer["w2"].append((h1, gh2))
         defer["w1"].append((z1, cond if has_cond else None, gh1))
     if k1 == 3 and k3 == 3 and smallmap_conv_ok(H, W, Hd, 0, Ch + Cc, N, bwd=True):
-        smallmap_conv(gh1, None, smallmap_pack(w1, H, W, True), Ch + Cc, 0, out1=gz[:, :Ch],
+        smallmap_conv(gh1, None, pk[10] if pk[10] is not None else smallmap_pack(w1, H, W, True), Ch + Cc, 0, out1=gz[:, :Ch],
                       out2=gcond if has_cond else None, cout_split=Ch, acc1=True, acc2=acc_cond)
     elif dgrad_small_ok(N, Hd, Ch + Cc, H, W, k1):
         conv3x3_smallcout(gh1, pk[1] if pk[1] is not None else pack_weight(w1, True), Ch + Cc, gz[:, :Ch],
@@ -931,7 +937,7 @@ class GlowStepFn(torch.autograd.Function):
         buffers kept fresh by the caller's pack plans (entries may be None: packed on the fly); the forward entries are
         bf16x3 packs and only used where that is the forward arithmetic."""
         out = actnorm_invconv_fwd(x, _f(an_bias), _f(an_logs), Wm.detach())
-        pk = tuple(packs) + (None,) * (8 - len(packs)) if packs is not None else (None,) * 8
+        pk = tuple(packs) + (None,) * (PACK_SLOTS - len(packs)) if packs is not None else (None,) * PACK_SLOTS
         ctx.packs = pk
         h1, h2, o, P, masks = _net_fwd(out, cond, w1, n1b, n1l, w2, n2b, n2l, w3, b3, l3, act, pk,
                                        want_masks=any(ctx.needs_input_grad))
@@ -984,7 +990,8 @@ class GlowLevelFn(torch.autograd.Function):
         assert len(flat) == STEP_NPARAM * Kn
         N, C, H, W = x.shape
         prm = [flat[STEP_NPARAM * k:STEP_NPARAM * (k + 1)] for k in range(Kn)]
-        pks = [(tuple(packs[k]) + (None,) * 8)[:8] if packs is not None and packs[k] is not None else (None,) * 8
+        pks = [(tuple(packs[k]) + (None,) * PACK_SLOTS)[:PACK_SLOTS] if packs is not None and packs[k] is not None
+               else (None,) * PACK_SLOTS
                for k in range(Kn)]
         want_masks = any(ctx.needs_input_grad)
         Wd = Wst.detach().contiguous()
@@ -1229,19 +1236,45 @@ def smallmap_supported(conv, H, W):
             and (conv.out_channels * H * W) % 8 == 0)
 
 
+class _SmallmapPackDesc(ctypes.Structure):   # rfn_smallmap_pack_desc (include/rfn_hip.h)
+    _fields_ = [("w", ctypes.c_void_p), ("packed", ctypes.c_void_p), ("Cout", ctypes.c_int), ("Cin", ctypes.c_int),
+                ("H", ctypes.c_int), ("W", ctypes.c_int), ("transpose", ctypes.c_int), ("pad_", ctypes.c_int)]
+
+
+# packs asked for but not launched yet: (descriptor fields, weight tensor kept alive).  The weights change every
+# optimizer step, so a training step re-packs ~60 matrices (latent nets, ConvLSTM, the 2x2 flow level); they are queued
+# here and go out in ONE launch (rfn_smallmap_pack_batched_bf16x3) right before the first kernel that reads any of them
+# -- every consumer (smallmap_dense / _pair / _conv) calls smallmap_pack_flush() first.
+_PACK_QUEUE = []
+
+
 def smallmap_pack(w, H, W, transpose):
-    """w [Cout, Cin, 3, 3] -> MFMA-fragment-ordered bf16 (hi, lo) dense matrix of the H x W map (rfn_smallmap_pack_bf16x3)"""
+    """w [Cout, Cin, 3, 3] -> MFMA-fragment-ordered bf16 (hi, lo) dense matrix of the H x W map.  The buffer is returned
+    at once; its contents exist after smallmap_pack_flush() (called by every consumer)."""
     Cout, Cin = int(w.shape[0]), int(w.shape[1])
     nbytes = int(L.load().rfn_smallmap_packed_size(Cout, Cin, H, W, 1 if transpose else 0))
     buf = torch.empty(nbytes // 4, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    L.call("rfn_smallmap_pack_bf16x3", L.dev(wc), _i(Cout), _i(Cin), _i(H), _i(W), _i(1 if transpose else 0), L.dev(buf))
+    L.dev(wc, "w")
+    _PACK_QUEUE.append(((wc.data_ptr(), buf.data_ptr(), Cout, Cin, int(H), int(W), 1 if transpose else 0, 0), wc, buf))
     return buf
+
+
+def smallmap_pack_flush():
+    """launch the queued packs (one launch per 64 matrices)"""
+    if not _PACK_QUEUE:
+        return
+    q = list(_PACK_QUEUE)
+    del _PACK_QUEUE[:]
+    arr = (_SmallmapPackDesc * len(q))(*[_SmallmapPackDesc(*f) for f, _, _ in q])
+    L.call("rfn_smallmap_pack_batched_bf16x3", ctypes.cast(arr, ctypes.c_void_p), _i(len(q)),
+           meta=_shell("rfn_smallmap_pack_bf16x3", q[0][2], sum(b.numel() for _, _, b in q) / max(q[0][2].numel(), 1)))
 
 
 def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slope_in=0.0, want_a_out=False, add=None):
     """out[B, n_channels, H, W] = a'[B, C, H, W] (as rows) x packed (+ bias, leaky_relu) -- rfn_smallmap_dense_bf16x3.
     With y: a' = a * (y > 0 ? 1 : slope_in); returns (out, a') when want_a_out."""
+    smallmap_pack_flush()
     a = a.contiguous()
     B, H, W = int(a.shape[0]), int(a.shape[2]), int(a.shape[3])
     K, HW = int(a.shape[1]) * H * W, H * W
@@ -1259,6 +1292,7 @@ def smallmap_dense_pair(a0, packed0, n_ch0, a1, packed1, n_ch1, bias0=None, bias
                         y0=None, y1=None, slope_in0=0.0, slope_in1=0.0, want_a_out=False, add0=None, add1=None):
     """two independent smallmap_dense products in ONE launch (rfn_smallmap_dense_pair_bf16x3): same batch and map size.
     Returns (out0, out1) or (out0, a0', out1, a1') with want_a_out.  add0 / add1: optional [B, n_ch, H, W] addends."""
+    smallmap_pack_flush()
     a0, a1 = a0.contiguous(), a1.contiguous()
     B, H, W = int(a0.shape[0]), int(a0.shape[2]), int(a0.shape[3])
     assert int(a1.shape[0]) == B and tuple(a1.shape[2:]) == (H, W)
@@ -1296,6 +1330,7 @@ def smallmap_conv_ok(H, W, C1, C2, Cout, N, bwd=False):
 def smallmap_conv(in1, in2, packed, Cout, ep_mode=0, p0=None, p1=None, act=0, out1=None, out2=None, cout_split=None,
                   acc1=False, acc2=False):
     """conv2d_raw's contract (3x3, pad 1) on an H*W <= 16 map through the dense split-precision product."""
+    smallmap_pack_flush()
     N, C1, H, W = in1.shape
     C2 = 0 if in2 is None else int(in2.shape[1])
     if cout_split is None:
@@ -1626,7 +1661,7 @@ class StepBatchNormActFn(torch.autograd.Function):
         x, mean, var, gm, bt = ctx.saved_tensors
         S, B, C, HW, eps, act, slope, affine, nscr = ctx.cfg
         if g is None:
-            return (None,) * 8
+            return (None,) * PACK_SLOTS
         g = g.contiguous()
         sums = torch.empty((nscr,), device=x.device, dtype=torch.float32)
         gx = torch.empty_like(x)
