@@ -115,6 +115,16 @@ int rfn_conv2d_fwd_bf16x6(const float* in1, long in1_ns, int C1, const float* in
                           int cout_split, int acc1, int acc2, int N, int H, int W, int ks, int ep_mode,
                           const float* p0, const float* p1, int act, rfn_stream_t stream);
 
+/* 3x3 / pad 1 convolution of an image with 1 .. 4 channels into 16 or 32 feature maps as plain fp32 FMAs (exact), one
+ * thread per pixel: the first convolution of the frame extractor (Utils/modules.py, the VGG block on the input frames;
+ * w is the torch weight [Cout][Cin][3][3], no epilogue), and its weight gradient for one input channel and 16 outputs
+ * (gw [16][1][3][3], accumulated with float atomics: the caller zeroes it). */
+int rfn_conv3x3_fewcin_supported(int Cin, int Cout);
+int rfn_conv3x3_fewcin_fwd_f32(const float* in, long in_ns, int Cin, const float* w, float* out, long out_ns, int Cout,
+                               int N, int H, int W, rfn_stream_t stream);
+int rfn_conv3x3_c1_wgrad16_f32(const float* in, long in_ns, const float* g, long g_ns, float* gw, int N, int H, int W,
+                               rfn_stream_t stream);
+
 /* Data-gradient convolution fused with the backward of the PRODUCER conv's Conv2dNorm epilogue (ActNorm + ActFun,
  * glow_modules.py:139-142 + Utils/modules.py:8-19): with y = act((u+b)*exp(logs)) saved from the forward pass,
  *   g  = conv(gin, wpk)                    (wpk packed with transpose_flip = 1 / mode 1)

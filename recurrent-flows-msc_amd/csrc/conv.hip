@@ -629,3 +629,124 @@ extern "C" int rfn_wgrad_finish_f32(const float* gwt, float* gw, int Cout, int C
     RFN_LAUNCH_CHECK();
     return 0;
 }
+
+
+// ------------------------------------------------------------------------------------------------ few input channels
+// 3x3 / pad 1 convolution of an image with 1 .. 4 channels into 16 or 32 feature maps (the first convolution of the
+// frame extractor, Utils/modules.py VGG block on the 64x64 frames): 9 Cin products per output value.  As an MFMA problem
+// it is a K = 9 .. 36 contraction padded to 16 / 48 with a 32-row tile around 16 outputs (0.32 ms forward, 0.35 ms for
+// the weight gradient at 640 frames, both at a tenth of the bytes' time); as plain fp32 FMAs it is exact and at the HBM
+// rate: one thread per pixel, the weights as 16-byte broadcast reads from LDS ([ci][tap][co]).
+template <int CO>
+__global__ __launch_bounds__(256) void conv3x3_fewcin_fwd_kernel(const float* __restrict__ in, long in_ns, int Cin,
+                                                                 const float* __restrict__ w, float* __restrict__ out,
+                                                                 long out_ns, int N, int H, int W) {
+    __shared__ __attribute__((aligned(16))) float ws[4 * 9 * CO];
+    for (int e = threadIdx.x; e < Cin * 9 * CO; e += 256) {
+        const int co = e % CO, r = e / CO, tap = r % 9, ci = r / 9;
+        ws[e] = w[((long)co * Cin + ci) * 9 + tap];
+    }
+    __syncthreads();
+    const long HW = (long)H * W, total = (long)N * HW;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long n = q / HW;
+        const int p = (int)(q - n * HW), y = p / W, x = p - y * W;
+        float acc[CO];
+#pragma unroll
+        for (int c = 0; c < CO; ++c) acc[c] = 0.f;
+        for (int ci = 0; ci < Cin; ++ci) {
+            const float* src = in + n * in_ns + (long)ci * HW;
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+                const float v = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(long)yy * W + xx] : 0.f;
+                const f32x4* w4 = reinterpret_cast<const f32x4*>(ws + (ci * 9 + t) * CO);
+#pragma unroll
+                for (int c4 = 0; c4 < CO / 4; ++c4) {
+                    const f32x4 wv = w4[c4];
+                    acc[4 * c4 + 0] = fmaf(wv[0], v, acc[4 * c4 + 0]);
+                    acc[4 * c4 + 1] = fmaf(wv[1], v, acc[4 * c4 + 1]);
+                    acc[4 * c4 + 2] = fmaf(wv[2], v, acc[4 * c4 + 2]);
+                    acc[4 * c4 + 3] = fmaf(wv[3], v, acc[4 * c4 + 3]);
+                }
+            }
+        }
+        float* dst = out + n * out_ns + p;
+#pragma unroll
+        for (int c = 0; c < CO; ++c) dst[(long)c * HW] = acc[c];
+    }
+}
+
+extern "C" int rfn_conv3x3_fewcin_supported(int Cin, int Cout) { return Cin >= 1 && Cin <= 4 && (Cout == 16 || Cout == 32); }
+
+extern "C" int rfn_conv3x3_fewcin_fwd_f32(const float* in, long in_ns, int Cin, const float* w, float* out, long out_ns,
+                                          int Cout, int N, int H, int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(in && w && out && N >= 0 && H > 0 && W > 0, -1);
+    RFN_CHECK_ARG(rfn_conv3x3_fewcin_supported(Cin, Cout), -2);
+    if (N == 0) return 0;
+    const long tot = (long)N * H * W;
+    const int grid = (int)((tot + 255) / 256 < 8192 ? (tot + 255) / 256 : 8192);
+    if (Cout == 16)
+        hipLaunchKernelGGL(conv3x3_fewcin_fwd_kernel<16>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, in_ns, Cin, w, out,
+                           out_ns, N, H, W);
+    else
+        hipLaunchKernelGGL(conv3x3_fewcin_fwd_kernel<32>, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, in_ns, Cin, w, out,
+                           out_ns, N, H, W);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+
+// Weight gradient of the same convolution for ONE input channel and 16 outputs: gw[co][tap] = sum over frames and pixels
+// of g[co][px] * in[px + tap] -- 144 running sums per thread over a grid-stride sweep, wave sums by DPP, one LDS row per
+// wave, 144 float atomics per workgroup (gw zeroed by the caller).
+__global__ __launch_bounds__(256) void conv3x3_c1_wgrad16_kernel(const float* __restrict__ in, long in_ns,
+                                                                 const float* __restrict__ g, long g_ns,
+                                                                 float* __restrict__ gw, int N, int H, int W) {
+    __shared__ float red[4][144];
+    float acc[16][9];
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) acc[c][t] = 0.f;
+    const long HW = (long)H * W, total = (long)N * HW;
+    for (long q = (long)blockIdx.x * 256 + threadIdx.x; q < total; q += (long)gridDim.x * 256) {
+        const long n = q / HW;
+        const int p = (int)(q - n * HW), y = p / W, x = p - y * W;
+        const float* src = in + n * in_ns;
+        float v[9];
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const int yy = y + t / 3 - 1, xx = x + t % 3 - 1;
+            v[t] = (yy >= 0 && yy < H && xx >= 0 && xx < W) ? src[(long)yy * W + xx] : 0.f;
+        }
+        const float* gp = g + n * g_ns + p;
+#pragma unroll
+        for (int c = 0; c < 16; ++c) {
+            const float gv = gp[(long)c * HW];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) acc[c][t] = fmaf(gv, v[t], acc[c][t]);
+        }
+    }
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int c = 0; c < 16; ++c)
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const float sum = wave_sum_dpp(acc[c][t]);
+            if (lane == 0) red[wave][c * 9 + t] = sum;
+        }
+    __syncthreads();
+    if (threadIdx.x < 144)
+        atomicAdd(&gw[threadIdx.x], (red[0][threadIdx.x] + red[1][threadIdx.x]) + (red[2][threadIdx.x] + red[3][threadIdx.x]));
+}
+
+extern "C" int rfn_conv3x3_c1_wgrad16_f32(const float* in, long in_ns, const float* g, long g_ns, float* gw, int N, int H,
+                                          int W, rfn_stream_t stream) {
+    RFN_CHECK_ARG(in && g && gw && N >= 0 && H > 0 && W > 0, -1);
+    if (N == 0) return 0;
+    const long tot = (long)N * H * W;
+    const int grid = (int)((tot + 255) / 256 < 1024 ? (tot + 255) / 256 : 1024);
+    hipLaunchKernelGGL(conv3x3_c1_wgrad16_kernel, dim3(grid), dim3(256), 0, (hipStream_t)stream, in, in_ns, g, g_ns, gw, N, H, W);
+    RFN_LAUNCH_CHECK();
+    return 0;
+}

@@ -96,6 +96,9 @@ SIGNATURES = {
     "rfn_latent_step_fwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i, _c_s],
     "rfn_latent_step_bwd_f32": [_c_f, _c_f, _c_f, _c_f, _c_f, _c_l, _c_f, _c_l, _c_f, _c_f, _c_f, _c_f, _c_f, _c_i, _c_i, _c_i,
                                 _c_s],
+    "rfn_conv3x3_fewcin_supported": [_c_i, _c_i],
+    "rfn_conv3x3_fewcin_fwd_f32": [_c_f, _c_l, _c_i, _c_f, _c_f, _c_l, _c_i, _c_i, _c_i, _c_i, _c_s],
+    "rfn_conv3x3_c1_wgrad16_f32": [_c_f, _c_l, _c_f, _c_l, _c_f, _c_i, _c_i, _c_i, _c_s],
     "rfn_smallmap_packed_size": [_c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_smallmap_pack_bf16x3": [_c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_s],
     "rfn_smallmap_pack_batched_bf16x3": [ctypes.c_void_p, _c_i, _c_s],

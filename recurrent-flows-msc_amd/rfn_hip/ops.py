@@ -696,6 +696,33 @@ class Squeeze2dFn(torch.autograd.Function):
         return squeeze2d_raw(g.contiguous(), not ctx.undo), None
 
 
+def fewcin_ok(in1, in2, w, ep_mode):
+    """the direct fp32 kernel for 3x3 convolutions of 1 .. 4-channel images (csrc/conv.hip, rfn_conv3x3_fewcin_fwd_f32)"""
+    return (in2 is None and ep_mode == 0 and tuple(w.shape[2:]) == (3, 3) and os.environ.get("RFN_FEWCIN") != "0"
+            and bool(L.load().rfn_conv3x3_fewcin_supported(int(w.shape[1]), int(w.shape[0]))))
+
+
+def conv3x3_fewcin(x, w):
+    N, Cin, H, W = x.shape
+    Cout = int(w.shape[0])
+    xp, xns = L.frames(x, "x")
+    out = torch.empty((N, Cout, H, W), device=x.device, dtype=torch.float32)
+    wc = w.detach().contiguous()
+    L.call("rfn_conv3x3_fewcin_fwd_f32", xp, _l(xns), _i(Cin), L.dev(wc), L.dev(out), _l(Cout * H * W), _i(Cout), _i(N),
+           _i(H), _i(W), meta=_shell("conv3x3_fewcin_fwd", out, 1.0 + Cin / Cout))
+    return out
+
+
+def conv3x3_c1_wgrad16(x, g):
+    N, _, H, W = x.shape
+    xp, xns = L.frames(x, "x")
+    gp, gns = L.frames(g, "g")
+    gw = torch.zeros((16, 1, 3, 3), device=x.device, dtype=torch.float32)
+    L.call("rfn_conv3x3_c1_wgrad16_f32", xp, _l(xns), gp, _l(gns), L.dev(gw), _i(N), _i(H), _i(W),
+           meta=_shell("conv3x3_c1_wgrad", g, 1.0 + 1.0 / 16))
+    return gw
+
+
 class ConvFn(torch.autograd.Function):
     """epilogue(conv(cat(in1, in2), w)) with the epilogue of rfn_conv2d_fwd_f32.
     p0/p1: ep_mode 1 -> (actnorm bias, actnorm logs); 2 -> (conv bias, logs); 3 -> (conv bias, None)."""
@@ -706,7 +733,10 @@ class ConvFn(torch.autograd.Function):
         p0f = None if p0 is None else p0.detach().reshape(-1).contiguous()
         p1f = None if p1 is None else p1.detach().reshape(-1).contiguous()
         fp = prec if prec is not None else fwd_prec(int(in1.shape[2]), int(in1.shape[3]))
-        y = conv2d_raw(in1, in2, pack_weight(w, prec=fp), Cout, ks, ep_mode, p0f, p1f, act, prec=fp)
+        if fewcin_ok(in1, in2, w, ep_mode):
+            y = conv3x3_fewcin(in1, w)   # the extractor's first convolution (1 .. 4 image channels): exact fp32 FMAs
+        else:
+            y = conv2d_raw(in1, in2, pack_weight(w, prec=fp), Cout, ks, ep_mode, p0f, p1f, act, prec=fp)
         ctx.save_for_backward(in1, in2, w, p1f, y)
         ctx.cfg = (ep_mode, act, None if p0 is None else p0.shape, None if p1 is None else p1.shape)
         return y
@@ -733,7 +763,10 @@ class ConvFn(torch.autograd.Function):
                 g2 = torch.empty(in2.shape, device=gy.device, dtype=torch.float32)
             conv2d_raw(gy, None, wt, Cin, ks, 0, None, None, 0, out1=g1, out2=g2, cout_split=C1)
         if ctx.needs_input_grad[2]:
-            gw = conv2d_wgrad(in1, in2, gy, Cout, ks)
+            if fewcin_ok(in1, in2, w, ep_mode) and Cin == 1 and Cout == 16:
+                gw = conv3x3_c1_wgrad16(in1, gy)
+            else:
+                gw = conv2d_wgrad(in1, in2, gy, Cout, ks)
         return g1, g2, gw, gp0, gp1, None, None, None
 
 

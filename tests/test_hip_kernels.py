@@ -420,6 +420,27 @@ def test_gemm_wgrad_tilings(K, M, Nc, F_, H, view):
     assert relerr(gw, ref.float()) < 2e-5
 
 
+@pytest.mark.parametrize("N,Cin,Cout,H,W", [(5, 1, 16, 64, 64), (3, 3, 32, 64, 64), (2, 1, 16, 7, 5), (2, 4, 16, 8, 8)])
+def test_conv3x3_few_input_channels(K, N, Cin, Cout, H, W):
+    """rfn_conv3x3_fewcin_fwd_f32 / rfn_conv3x3_c1_wgrad16_f32 (the extractor's first convolution: 1 .. 4 image channels
+    into 16 / 32 maps as plain fp32 FMAs) through rfn_hip.ops.ConvFn against F.conv2d and its gradients: fp32 arithmetic,
+    so 1e-6 forward; the weight gradient sums 10^4 .. 10^5 products per entry in another order: 2e-5."""
+    g = torch.Generator().manual_seed(90)
+    x = torch.randn(N, Cin, H, W, generator=g)
+    w = (torch.randn(Cout, Cin, 3, 3, generator=g) * 0.3)
+    gy = torch.randn(N, Cout, H, W, generator=g)
+    xr, wr = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    ref = F.conv2d(xr, wr, padding=1)
+    ref.backward(gy.double())
+    xc, wc = cu(x).requires_grad_(True), cu(w).requires_grad_(True)
+    assert K.fewcin_ok(xc, None, wc, 0)
+    y = K.conv_ep(xc, None, wc, None, None, 0, 0)
+    assert relerr(y, ref.detach()) < 1e-6
+    y.backward(cu(gy))
+    assert relerr(wc.grad, wr.grad) < 2e-5
+    assert relerr(xc.grad, xr.grad) < 2e-5 * ctol()
+
+
 @pytest.mark.parametrize("G,N,C1,C2,Cout,S,ks", [(3, 600, 8, 64, 256, 8, 3), (4, 40, 2, 16, 256, 32, 3), (3, 50, 4, 0, 64, 8, 3),
                                                  (3, 70, 256, 0, 256, 8, 1), (2, 60, 256, 0, 16, 8, 3), (3, 33, 16, 128, 256, 4, 3)])
 def test_conv2d_wgrad_grouped(K, G, N, C1, C2, Cout, S, ks):
