@@ -57,7 +57,7 @@ def run(N, C, S):
 
     def fwd():
         L.call("rfn_glow_shell_fwd_f32", L.dev(z), _l(C * HW), None, L.dev(o), _l(C * HW), None, None, None, None, None,
-               L.dev(ldp), _i(1), L.dev(bias), L.dev(logs), L.dev(Wm), L.dev(zn), _l(C * HW), _i(0), _i(N), _i(C), _i(S), _i(S))
+               L.dev(ldp), _i(1), L.dev(bias), L.dev(logs), L.dev(Wm), L.dev(zn), _l(C * HW), _i(1), _i(N), _i(C), _i(S), _i(S))
 
     tb, tf = timed(bwd), timed(fwd)
     by = 4.0 * N * C * HW
