@@ -148,6 +148,8 @@ typedef struct {
     int Cout, Cin, ks, mode;
 } rfn_pack_desc;
 int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_stream_t stream);
+/* the same for descriptors in HOST memory (packs queued by the host between two launches): 64 per launch */
+int rfn_pack_conv_weights_hostdescs_bf16x3(const void* descs_host, int n, rfn_stream_t stream);
 
 /* ---- a5 fused  AffineCoupling.net forward for the shallow levels (Flow/glow_modules.py:232-238 with :119-121 and
  * :139-142), csrc/coupling_po.hip: conv3x3 -> ActNorm -> act -> conv1x1 -> ActNorm -> act -> tap-expanded conv3x3 in

@@ -315,7 +315,7 @@ class RFN(nn.Module):
                 for _ in range(2):  # warm-up on the capture path (lazy per-stream state, generation cache, MIOpen)
                     self._gen_step(*static_in[:4], static_in[4:], kl_temp)
             torch.cuda.current_stream().wait_stream(side)
-            K.smallmap_pack_flush()   # (nothing queued outside may be launched -- and replayed -- inside the capture)
+            K.flush_packs()   # (nothing queued outside may be launched -- and replayed -- inside the capture)
             graph = torch.cuda.CUDAGraph()
             with torch.cuda.graph(graph):
                 static_out = self._gen_step(*static_in[:4], static_in[4:], kl_temp)

@@ -196,7 +196,7 @@ class Solver(object):
                     self.optimizer.zero_grad(set_to_none=True)
             torch.cuda.current_stream().wait_stream(side)
             self.optimizer.zero_grad(set_to_none=True)
-            K.smallmap_pack_flush()   # (nothing queued outside may be launched -- and replayed -- inside the capture)
+            K.flush_packs()   # (nothing queued outside may be launched -- and replayed -- inside the capture)
             g = torch.cuda.CUDAGraph()
             with torch.cuda.graph(g):
                 self._graph_body()

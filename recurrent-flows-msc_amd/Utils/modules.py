@@ -132,6 +132,15 @@ def per_step_batchnorm_act(bn, x, steps, act_code, slope):
 def run_time_batched(seq, x, steps):
     """run an nn.Sequential on a step-major time-batched tensor, BatchNorm statistics per step."""
     mods = list(seq)
+    # the weight packs of every convolution of the stack (forward arithmetic; data gradient when one will be asked for)
+    # are queued up front: they leave in one launch before the first convolution (rfn_hip.ops.pack_weight)
+    packs = {}
+    if x.is_cuda and x.dtype == torch.float32 and K.CONV_PRECISION != "f32" and K.bwd_b3():
+        fpre = "bf16x6"
+        for m in mods:
+            if _own_conv(m, x) and not K.fewcin_ok(x, None, m.weight, 0):
+                packs[m] = (K.pack_weight(m.weight, prec=fpre),
+                            K.pack_weight(m.weight, flip=True) if torch.is_grad_enabled() else None)
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -153,7 +162,7 @@ def run_time_batched(seq, x, steps):
             # (tests/test_hip_modules.py::test_forward_pass_is_bit_reproducible).  RFN_VGG_CONV=miopen: the old route.
             # (these layers were fp32 on MIOpen: fp32-grade here too, also in the all-bf16x3 test arithmetic)
             x = K.conv_ep(x.contiguous(), None, m.weight, None, None, 0, 0,
-                          prec="f32" if K.CONV_PRECISION == "f32" else "bf16x6")
+                          prec="f32" if K.CONV_PRECISION == "f32" else "bf16x6", packs=packs.get(m))
         else:
             x = m(x)
         i += 1

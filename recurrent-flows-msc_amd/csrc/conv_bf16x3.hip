@@ -105,8 +105,13 @@ struct PackDesc {  // mirrors rfn_pack_desc in include/rfn_hip.h
     float* wpk;
     int Cout, Cin, ks, mode;
 };
-__global__ void pack_weights_batched_b3_kernel(const PackDesc* __restrict__ descs) {
-    const PackDesc d = descs[blockIdx.y];
+__device__ __forceinline__ void pack_weights_one(const PackDesc d);
+__global__ void pack_weights_batched_b3_kernel(const PackDesc* __restrict__ descs) { pack_weights_one(descs[blockIdx.y]); }
+// the same with the descriptors by value in the kernel arguments (packs queued by the host between two launches)
+#define PACK_TABLE_MAX 64
+struct PackTable { PackDesc d[PACK_TABLE_MAX]; };
+__global__ void pack_weights_table_b3_kernel(const PackTable t) { pack_weights_one(t.d[blockIdx.y]); }
+__device__ __forceinline__ void pack_weights_one(const PackDesc d) {
     const int T_src = d.ks * d.ks;
     const int NPL = (d.mode & 4) ? 3 : 2, mode = d.mode & 3;  // (mode + 4: three planes = bf16x6)
     int Co_l, Ci_l, T;
@@ -154,6 +159,23 @@ extern "C" int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, in
     if (n == 0) return 0;
     hipLaunchKernelGGL(pack_weights_batched_b3_kernel, dim3(24, n), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const PackDesc*>(descs_device));
+    RFN_LAUNCH_CHECK();
+    return 0;
+}
+/* n descriptors in HOST memory: ceil(n / 64) launches, the table travels in the kernel arguments */
+extern "C" int rfn_pack_conv_weights_hostdescs_bf16x3(const void* descs_host, int n, rfn_stream_t stream) {
+    RFN_CHECK_ARG(descs_host && n >= 0, -1);
+    const PackDesc* d = reinterpret_cast<const PackDesc*>(descs_host);
+    for (int i = 0; i < n; ++i)
+        RFN_CHECK_ARG(d[i].w && d[i].wpk && d[i].Cout > 0 && d[i].Cin > 0 && (d[i].ks == 1 || d[i].ks == 3) &&
+                      ((uintptr_t)d[i].wpk & 15) == 0, -2);
+    for (int i0 = 0; i0 < n; i0 += PACK_TABLE_MAX) {
+        const int m = n - i0 < PACK_TABLE_MAX ? n - i0 : PACK_TABLE_MAX;
+        PackTable t;
+        memset(&t, 0, sizeof(t));
+        for (int i = 0; i < m; ++i) t.d[i] = d[i0 + i];
+        hipLaunchKernelGGL(pack_weights_table_b3_kernel, dim3(24, m), dim3(256), 0, (hipStream_t)stream, t);
+    }
     RFN_LAUNCH_CHECK();
     return 0;
 }

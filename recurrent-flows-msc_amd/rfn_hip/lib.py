@@ -102,6 +102,7 @@ SIGNATURES = {
     "rfn_smallmap_packed_size": [_c_i, _c_i, _c_i, _c_i, _c_i],
     "rfn_smallmap_pack_bf16x3": [_c_f, _c_i, _c_i, _c_i, _c_i, _c_i, _c_f, _c_s],
     "rfn_smallmap_pack_batched_bf16x3": [ctypes.c_void_p, _c_i, _c_s],
+    "rfn_pack_conv_weights_hostdescs_bf16x3": [ctypes.c_void_p, _c_i, _c_s],
     "rfn_smallmap_dense_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i,
                                   _c_i, _c_i, _c_i, _c_s],
     "rfn_smallmap_dense_pair_bf16x3": [_c_f, _c_f, ctypes.c_float, _c_f, _c_f, _c_f, _c_i, ctypes.c_float, _c_f, _c_f, _c_i,
@@ -156,8 +157,17 @@ def load():
 PROFILE = None
 
 
+# work queued by rfn_hip.ops that must be launched before the next kernel (weight packs collected into one launch): a
+# callable, run -- once -- at the top of the next call()
+PENDING_FLUSH = None
+
+
 def call(name, *args, meta=None):
     """Invoke an int-returning entry point on the current torch stream; raise on a non-zero code."""
+    global PENDING_FLUSH
+    if PENDING_FLUSH is not None:
+        flush, PENDING_FLUSH = PENDING_FLUSH, None
+        flush()
     lib = load()
     cur = torch.cuda.current_stream()
     stream = ctypes.c_void_p(cur.cuda_stream)

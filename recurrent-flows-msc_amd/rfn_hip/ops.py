@@ -139,9 +139,21 @@ def invconv_actnorm_rev(z, bias, logs, Winv):
     return x
 
 
+class _ConvPackDesc(ctypes.Structure):   # rfn_pack_desc (include/rfn_hip.h)
+    _fields_ = [("w", ctypes.c_void_p), ("wpk", ctypes.c_void_p), ("Cout", ctypes.c_int), ("Cin", ctypes.c_int),
+                ("ks", ctypes.c_int), ("mode", ctypes.c_int)]
+
+
+# split-precision conv-weight packs asked for but not launched yet; they leave in ONE launch
+# (rfn_pack_conv_weights_hostdescs_bf16x3) before the next kernel of the library (rfn_hip.lib.PENDING_FLUSH)
+_CONV_PACK_QUEUE = []
+
+
 def pack_weight(w, flip=False, prec=None):
     """Pack a torch-layout conv weight [Cout,Cin,k,k] for the MFMA conv kernel (flip=True: data-gradient conv).
-    One streaming kernel over the packed buffer; done per call (weights change every optimizer step).
+    Done per call (weights change every optimizer step).  The split-precision packs are QUEUED: the buffer is returned at
+    once, its contents exist when the next kernel of the library is launched (every pack queued until then shares one
+    launch: a module that knows its convolutions up front -- the extractor / upscaler -- asks for all of them first).
     prec: 'bf16x3' | 'bf16x6' | 'f32' (default: the gradient arithmetic, which is what un-annotated callers are)."""
     Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
     prec = prec if prec is not None else ("bf16x3" if bwd_b3() else "f32")
@@ -149,9 +161,25 @@ def pack_weight(w, flip=False, prec=None):
     size = getattr(L.load(), "rfn_packed_weight_size" + sfx)(Cout, Cin, ks)
     wpk = torch.empty(size, device=w.device, dtype=torch.float32)
     wc = w.detach().contiguous()
-    L.call("rfn_pack_conv_weight" + (sfx if sfx else "_f32"), L.dev(wc, "w"), L.dev(wpk), _i(Cout), _i(Cin), _i(ks),
-           _i(1 if flip else 0))
+    if prec == "f32":
+        L.call("rfn_pack_conv_weight_f32", L.dev(wc, "w"), L.dev(wpk), _i(Cout), _i(Cin), _i(ks), _i(1 if flip else 0))
+        return wpk
+    L.dev(wc, "w")
+    _CONV_PACK_QUEUE.append(((wc.data_ptr(), wpk.data_ptr(), Cout, Cin, ks, (1 if flip else 0) + (4 if prec == "bf16x6" else 0)),
+                             wc, wpk))
+    L.PENDING_FLUSH = flush_packs
     return wpk
+
+
+def flush_packs():
+    """launch every queued weight pack (conv packs and small-map dense packs), one launch per kind and 64 matrices"""
+    if _CONV_PACK_QUEUE:
+        q = list(_CONV_PACK_QUEUE)
+        del _CONV_PACK_QUEUE[:]
+        arr = (_ConvPackDesc * len(q))(*[_ConvPackDesc(*f) for f, _, _ in q])
+        L.call("rfn_pack_conv_weights_hostdescs_bf16x3", ctypes.cast(arr, ctypes.c_void_p), _i(len(q)),
+               meta=_shell("rfn_pack_conv_weights_batched_bf16x3", q[0][2], sum(b.numel() for _, _, b in q) / max(q[0][2].numel(), 1)))
+    smallmap_pack_flush()
 
 
 def conv2d_dgrad_act(gin, wpk_flip, y, logs, act, Cout, ks, arena=None):
@@ -728,15 +756,18 @@ class ConvFn(torch.autograd.Function):
     p0/p1: ep_mode 1 -> (actnorm bias, actnorm logs); 2 -> (conv bias, logs); 3 -> (conv bias, None)."""
 
     @staticmethod
-    def forward(ctx, in1, in2, w, p0, p1, ep_mode, act, prec=None):
+    def forward(ctx, in1, in2, w, p0, p1, ep_mode, act, prec=None, packs=None):
+        # packs: (forward pack, data-gradient pack or None) queued by the caller (run_time_batched), else packed here
         Cout, ks = int(w.shape[0]), int(w.shape[2])
+        ctx.pk_b = None if packs is None else packs[1]
         p0f = None if p0 is None else p0.detach().reshape(-1).contiguous()
         p1f = None if p1 is None else p1.detach().reshape(-1).contiguous()
         fp = prec if prec is not None else fwd_prec(int(in1.shape[2]), int(in1.shape[3]))
         if fewcin_ok(in1, in2, w, ep_mode):
             y = conv3x3_fewcin(in1, w)   # the extractor's first convolution (1 .. 4 image channels): exact fp32 FMAs
         else:
-            y = conv2d_raw(in1, in2, pack_weight(w, prec=fp), Cout, ks, ep_mode, p0f, p1f, act, prec=fp)
+            y = conv2d_raw(in1, in2, packs[0] if packs is not None and packs[0] is not None else pack_weight(w, prec=fp),
+                           Cout, ks, ep_mode, p0f, p1f, act, prec=fp)
         ctx.save_for_backward(in1, in2, w, p1f, y)
         ctx.cfg = (ep_mode, act, None if p0 is None else p0.shape, None if p1 is None else p1.shape)
         return y
@@ -756,7 +787,7 @@ class ConvFn(torch.autograd.Function):
         C1 = int(in1.shape[1])
         need1, need2 = ctx.needs_input_grad[0], in2 is not None and ctx.needs_input_grad[1]
         if need1 or need2:
-            wt = pack_weight(w, flip=True)
+            wt = ctx.pk_b if ctx.pk_b is not None else pack_weight(w, flip=True)
             N, _, H, W = in1.shape
             g1 = torch.empty(in1.shape, device=gy.device, dtype=torch.float32)
             if in2 is not None:
@@ -767,12 +798,13 @@ class ConvFn(torch.autograd.Function):
                 gw = conv3x3_c1_wgrad16(in1, gy)
             else:
                 gw = conv2d_wgrad(in1, in2, gy, Cout, ks)
-        return g1, g2, gw, gp0, gp1, None, None, None
+        return g1, g2, gw, gp0, gp1, None, None, None, None
 
 
-def conv_ep(in1, in2, w, p0, p1, ep_mode, act, prec=None):
-    """`prec` (optional): forward arithmetic ('bf16x3' | 'bf16x6' | 'f32') instead of this map size's default"""
-    return ConvFn.apply(in1, in2, w, p0, p1, ep_mode, act, prec)
+def conv_ep(in1, in2, w, p0, p1, ep_mode, act, prec=None, packs=None):
+    """`prec` (optional): forward arithmetic ('bf16x3' | 'bf16x6' | 'f32') instead of this map size's default;
+    `packs` (optional): (forward pack in that arithmetic, data-gradient pack or None) already queued by the caller"""
+    return ConvFn.apply(in1, in2, w, p0, p1, ep_mode, act, prec, packs)
 
 
 def _f(t):
@@ -1290,6 +1322,7 @@ def smallmap_pack(w, H, W, transpose):
     wc = w.detach().contiguous()
     L.dev(wc, "w")
     _PACK_QUEUE.append(((wc.data_ptr(), buf.data_ptr(), Cout, Cin, int(H), int(W), 1 if transpose else 0, 0), wc, buf))
+    L.PENDING_FLUSH = flush_packs
     return buf
 
 
