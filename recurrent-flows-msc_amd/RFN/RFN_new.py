@@ -172,7 +172,7 @@ class RFN(nn.Module):
             DBG.check("feat%d" % j, f)
         DBG.check("ht_last", store_ht[T - 1] if len(store_ht) >= T else store_ht[-1])
 
-        kl_loss = 0
+        kl_loss, kl_terms = 0, []
         st_mean, st_std, st_zx = [], [], []
         base_t, noise_t = [], []
         # all 2(T-1) reparameterisation draws of the loop in one launch
@@ -211,7 +211,7 @@ class RFN(nn.Module):
             if draws is not None:
                 noise_t.append(draws.pop(0).to(dev))
             if self.D == 1:
-                kl_loss = kl_loss + kl_t
+                kl_terms.append(kl_t)   # (summed after the loop: one stack + one reduction instead of T-1 adds each way)
             zprev, zxprev = zt, zxt
 
         # ---- the decoder: all B*(T-1) frames in one call, t-major
@@ -239,6 +239,8 @@ class RFN(nn.Module):
         _, nll = self.flow.log_prob(xs, conds, base, logdet, noise)
         DBG.check("nll", nll)
         nll_loss = nll.view(T - 1, B).sum(0)
+        if kl_terms:
+            kl_loss = torch.stack(kl_terms).sum(0)
 
         if self.D > 1:  # overshooting (RFN_new.py:213-240)
             kl_loss = 0

@@ -648,16 +648,19 @@ def zeros_conv_wgrad(x, g_pre, C, ks, arena=None):
     return gw.view(3, 3, C, Cin).permute(2, 3, 0, 1).contiguous()
 
 
-def conv_epilogue_bwd(y, gy, logs, ep_mode, act, want_gl=True, arena=None):
-    """in-place on gy: gy <- gu ; returns (gu, gb, gl)"""
+def conv_epilogue_bwd(y, gy, logs, ep_mode, act, want_gl=True, arena=None, inplace=True):
+    """gu from gy (in place on gy, or -- inplace=False: gy is somebody else's tensor -- into a new one); returns
+    (gu, gb, gl).  gb / gl are accumulated by the kernel: one zero fill for both."""
     N, C = gy.shape[0], gy.shape[1]
     yp, yns = (None, 0) if y is None else L.frames(y, "y")
     gp, gns = L.frames(gy, "gy")
-    gb = _zeros(arena, C, device=gy.device)
-    gl = _zeros(arena, C, device=gy.device) if want_gl else None
-    L.call("rfn_conv_epilogue_bwd_f32", yp, _l(yns), gp, _l(gns), gp, _l(gns), L.dev(logs), L.dev(gb), L.dev(gl),
+    gu = gy if inplace else torch.empty_like(gy, memory_format=torch.contiguous_format)
+    up, uns = L.frames(gu, "gu")
+    gbl = _zeros(arena, 2 if want_gl else 1, C, device=gy.device)
+    gb, gl = gbl[0], (gbl[1] if want_gl else None)
+    L.call("rfn_conv_epilogue_bwd_f32", yp, _l(yns), gp, _l(gns), up, _l(uns), L.dev(logs), L.dev(gb), L.dev(gl),
            _i(N), _i(C), _i(_hw(gy)), _i(ep_mode), _i(act), meta=_shell("conv_epilogue_bwd", gy, 3))
-    return gy, gb, gl
+    return gu, gb, gl
 
 
 def affine_coupling_(z, o, scale, scale_shift, logdet, clamp_type, reverse):
@@ -777,10 +780,11 @@ class ConvFn(torch.autograd.Function):
         in1, in2, w, p1f, y = ctx.saved_tensors
         ep_mode, act, p0shape, p1shape = ctx.cfg
         Cout, Cin, ks = int(w.shape[0]), int(w.shape[1]), int(w.shape[2])
-        gy = gy.contiguous().clone() if ep_mode != 0 else gy.contiguous()
+        gy = gy.contiguous()
         gp0 = gp1 = None
         if ep_mode != 0:
-            gy, gb, gl = conv_epilogue_bwd(y if ep_mode != 3 else None, gy, p1f, ep_mode, act, ep_mode != 3)
+            # (out of place: the incoming gradient belongs to autograd)
+            gy, gb, gl = conv_epilogue_bwd(y if ep_mode != 3 else None, gy, p1f, ep_mode, act, ep_mode != 3, inplace=False)
             gp0 = gb.view(p0shape)
             gp1 = gl.view(p1shape) if gl is not None else None
         g1 = g2 = gw = None
