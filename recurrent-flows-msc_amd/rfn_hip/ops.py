@@ -177,8 +177,7 @@ def flush_packs():
         q = list(_CONV_PACK_QUEUE)
         del _CONV_PACK_QUEUE[:]
         arr = (_ConvPackDesc * len(q))(*[_ConvPackDesc(*f) for f, _, _ in q])
-        L.call("rfn_pack_conv_weights_hostdescs_bf16x3", ctypes.cast(arr, ctypes.c_void_p), _i(len(q)),
-               meta=_shell("rfn_pack_conv_weights_batched_bf16x3", q[0][2], sum(b.numel() for _, _, b in q) / max(q[0][2].numel(), 1)))
+        L.call("rfn_pack_conv_weights_hostdescs_bf16x3", ctypes.cast(arr, ctypes.c_void_p), _i(len(q)))
     smallmap_pack_flush()
 
 
@@ -1337,8 +1336,7 @@ def smallmap_pack_flush():
     q = list(_PACK_QUEUE)
     del _PACK_QUEUE[:]
     arr = (_SmallmapPackDesc * len(q))(*[_SmallmapPackDesc(*f) for f, _, _ in q])
-    L.call("rfn_smallmap_pack_batched_bf16x3", ctypes.cast(arr, ctypes.c_void_p), _i(len(q)),
-           meta=_shell("rfn_smallmap_pack_bf16x3", q[0][2], sum(b.numel() for _, _, b in q) / max(q[0][2].numel(), 1)))
+    L.call("rfn_smallmap_pack_batched_bf16x3", ctypes.cast(arr, ctypes.c_void_p), _i(len(q)))
 
 
 def smallmap_dense(a, packed, n_channels, bias=None, slope_out=None, y=None, slope_in=0.0, want_a_out=False, add=None):
