@@ -24,3 +24,10 @@ DOM=$(python -c "import json; print(json.loads(open('gpurun_out/b.json').read().
 echo "dominant kernel template: $DOM"
 python tools/pmc_traffic.py gpurun_out/pmc_f gpurun_out/pmc_w "$DOM" gpurun_out/pmc_dominant_traffic.json
 rm -f gpurun_out/pmc_f/*/*counter_collection.csv gpurun_out/pmc_w/*/*counter_collection.csv
+# matrix-pipe utilisation per kernel (SQ_VALU_MFMA_BUSY_CYCLES / GRBM_GUI_ACTIVE): one more --pmc pass
+mkdir -p gpurun_out/pmc_m
+cd /tmp
+rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $GRAFT_REPO_ROOT/gpurun_out/pmc_m -o m -- python3 $GRAFT_REPO_ROOT/bench.py --child --steps 2 --warmup 2 --no-graph --no-cpu-baseline --no-roofline --secondary --no-parity > $GRAFT_REPO_ROOT/gpurun_out/pmc_m.log 2>&1
+cd $GRAFT_REPO_ROOT
+python tools/pmc_mfma.py gpurun_out/pmc_m gpurun_out/pmc_mfma_by_kernel.csv
+rm -f gpurun_out/pmc_m/*/*counter_collection.csv gpurun_out/pmc_m/*counter_collection.csv
