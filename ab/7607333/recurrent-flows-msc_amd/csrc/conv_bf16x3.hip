@@ -173,19 +173,8 @@ extern "C" int rfn_pack_conv_weights_hostdescs_bf16x3(const void* descs_host, in
         const int m = n - i0 < PACK_TABLE_MAX ? n - i0 : PACK_TABLE_MAX;
         PackTable t;
         memset(&t, 0, sizeof(t));
-        long most = 0;   // blocks per matrix follow the LARGEST one of the launch (a 2 M-element weight on 24 blocks is 0.1 ms)
-        for (int i = 0; i < m; ++i) {
-            t.d[i] = d[i0 + i];
-            const int T_src = t.d[i].ks * t.d[i].ks, mode = t.d[i].mode & 3;
-            const int Co_l = mode == 0 ? t.d[i].Cout : (mode == 1 ? t.d[i].Cin : T_src * t.d[i].Cout);
-            const int Ci_l = mode == 1 ? t.d[i].Cout : t.d[i].Cin, T = mode == 2 ? 1 : T_src;
-            const long total = (long)((Ci_l + 15) / 16) * T * 2 * (((Co_l + 255) / 256) * 256);
-            most = total > most ? total : most;
-        }
-        int gx = (int)((most + 255) / 256);
-        gx = gx < 24 ? 24 : (gx > 1024 ? 1024 : gx);
-        while ((long)gx * m > 16384) gx = (gx + 1) / 2;   // (many matrices: the launch stays a few thousand blocks)
-        hipLaunchKernelGGL(pack_weights_table_b3_kernel, dim3(gx, m), dim3(256), 0, (hipStream_t)stream, t);
+        for (int i = 0; i < m; ++i) t.d[i] = d[i0 + i];
+        hipLaunchKernelGGL(pack_weights_table_b3_kernel, dim3(24, m), dim3(256), 0, (hipStream_t)stream, t);
     }
     RFN_LAUNCH_CHECK();
     return 0;
