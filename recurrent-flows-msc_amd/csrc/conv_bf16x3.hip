@@ -157,7 +157,7 @@ __device__ __forceinline__ void pack_weights_one(const PackDesc d) {
 extern "C" int rfn_pack_conv_weights_batched_bf16x3(const void* descs_device, int n, rfn_stream_t stream) {
     RFN_CHECK_ARG(descs_device && n >= 0, -1);
     if (n == 0) return 0;
-    hipLaunchKernelGGL(pack_weights_batched_b3_kernel, dim3(24, n), dim3(256), 0, (hipStream_t)stream,
+    hipLaunchKernelGGL(pack_weights_batched_b3_kernel, dim3(96, n), dim3(256), 0, (hipStream_t)stream,
                        reinterpret_cast<const PackDesc*>(descs_device));
     RFN_LAUNCH_CHECK();
     return 0;
