@@ -129,18 +129,26 @@ def per_step_batchnorm_act(bn, x, steps, act_code, slope):
     return y
 
 
-def run_time_batched(seq, x, steps):
-    """run an nn.Sequential on a step-major time-batched tensor, BatchNorm statistics per step."""
-    mods = list(seq)
-    # the weight packs of every convolution of the stack (forward arithmetic; data gradient when one will be asked for)
-    # are queued up front: they leave in one launch before the first convolution (rfn_hip.ops.pack_weight)
+def queue_conv_packs(seqs, x):
+    """{conv module: (forward pack, data-gradient pack or None)} for every convolution of the nn.Sequentials `seqs` that
+    runs on the package's kernels (forward arithmetic; data gradient when one will be asked for).  The packs are QUEUED
+    (rfn_hip.ops.pack_weight): asked for up front, all of a network's leave in one launch before its first convolution."""
     packs = {}
     if x.is_cuda and x.dtype == torch.float32 and K.CONV_PRECISION != "f32" and K.bwd_b3():
-        fpre = "bf16x6"
-        for m in mods:
-            if _own_conv(m, x) and not K.fewcin_ok(x, None, m.weight, 0):
-                packs[m] = (K.pack_weight(m.weight, prec=fpre),
-                            K.pack_weight(m.weight, flip=True) if torch.is_grad_enabled() else None)
+        for seq in seqs:
+            for m in seq:
+                if _own_conv(m, x) and not K.fewcin_ok(x, None, m.weight, 0):
+                    packs[m] = (K.pack_weight(m.weight, prec="bf16x6"),
+                                K.pack_weight(m.weight, flip=True) if torch.is_grad_enabled() else None)
+    return packs
+
+
+def run_time_batched(seq, x, steps, packs=None):
+    """run an nn.Sequential on a step-major time-batched tensor, BatchNorm statistics per step.
+    packs: queue_conv_packs of (at least) this stack, when the caller has asked for a whole network's at once."""
+    mods = list(seq)
+    if packs is None:
+        packs = queue_conv_packs([seq], x)
     i = 0
     while i < len(mods):
         m = mods[i]
@@ -283,8 +291,9 @@ class VGG_downscaler(nn.Module):
     def forward_steps(self, x, steps):
         """all `steps` per-timestep calls of forward() at once on a step-major [steps*B, C, H, W] tensor."""
         outputs = []
+        packs = queue_conv_packs(self.l_nets, x)
         for i in range(self.L):
-            x = run_time_batched(self.l_nets[i], x, steps)
+            x = run_time_batched(self.l_nets[i], x, steps, packs)
             if self.skip_con:
                 outputs.append(x)
             else:
@@ -349,12 +358,13 @@ class VGG_upscaler(nn.Module):
         """all `steps` per-timestep calls of forward() at once (step-major time-batched x and skip maps)."""
         outputs = []
         rev = list(reversed(skip_list)) if self.skips else None
+        packs = queue_conv_packs(list(self.upscales_nets) + list(self.l_nets), x)
         for i in range(self.L):
             if i > 0:
-                x = run_time_batched(self.upscales_nets[i - 1], x, steps)
+                x = run_time_batched(self.upscales_nets[i - 1], x, steps, packs)
             if self.skips:
                 x = torch.cat((x, rev[i]), dim=1)
-            x = run_time_batched(self.l_nets[i], x, steps)
+            x = run_time_batched(self.l_nets[i], x, steps, packs)
             outputs.append(x)
         outputs.reverse()
         return outputs
