@@ -117,7 +117,7 @@ int rfn_conv2d_fwd_bf16x6(const float* in1, long in1_ns, int C1, const float* in
 
 /* 3x3 / pad 1 convolution of an image with 1 .. 4 channels into 16 or 32 feature maps as plain fp32 FMAs (exact), one
  * thread per pixel: the first convolution of the frame extractor (Utils/modules.py:81, VGG_downscaler's 3x3 / stride 1 /
- * bias-free convolution applied to the input frames, called from RFN/RFN_new.py:131-160;
+ * bias-free convolution applied to the input frames, called from RFN/RFN_new.py:127;
  * w is the torch weight [Cout][Cin][3][3], no epilogue), and its weight gradient for one input channel and 16 outputs
  * (gw [16][1][3][3], accumulated with float atomics: the caller zeroes it). */
 int rfn_conv3x3_fewcin_supported(int Cin, int Cout);
